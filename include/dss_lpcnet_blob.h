@@ -1,0 +1,63 @@
+/*
+ * include/dss_lpcnet_blob.h -- on-disk / in-memory layout of an LPCNet weight blob.
+ *
+ * The reference links xiph/LPCNet's generated `src/nnet_data.c` (listed at
+ * extensions/lpcnet/setup.py:34-36; the file itself is fetched from the network by xiph's
+ * autogen.sh and is absent from /root/reference).  This build keeps the same tensors in one
+ * flat little-endian blob so that weights are data, not compiled code: a blob converted from a
+ * real nnet_data.c drops in without rebuilding the library.
+ *
+ * Layout: dss_blob_header, then the sections below, tightly packed, in this order.
+ * All sections are float32 except gru_a_idx (int32).  Dense matrices are INPUT-major
+ * ([n_in][n_out], the layout xiph's sgemv_accum reads: weights[j*stride + i]).
+ *
+ *   embed_pitch      [pitch_max][embed_pitch_dim]
+ *   conv1_w          [3*(nb_features+embed_pitch_dim)][conv1_out]     conv1_b [conv1_out]
+ *   conv2_w          [3*conv1_out][conv2_out]                         conv2_b [conv2_out]
+ *   dense1_w         [conv2_out][dense1_out]                          dense1_b[dense1_out]
+ *   dense2_w         [dense1_out][dense2_out]                         dense2_b[dense2_out]
+ *   gru_a_dense_w    [dense2_out][3*gru_a]                            gru_a_dense_b[3*gru_a]
+ *   gru_b_dense_w    [dense2_out][3*gru_b]                            gru_b_dense_b[3*gru_b]
+ *   embed_sig        [256][3*gru_a]
+ *   embed_pred       [256][3*gru_a]
+ *   embed_exc        [256][3*gru_a]
+ *   gru_a_rbias      [3*gru_a]         recurrent bias (gru->bias[3N..6N) in xiph's layout)
+ *   gru_a_diag       [3*gru_a]         diagonal of the recurrent matrix, per gate
+ *   gru_a_idx        int32[sparse_idx_len]   for each group of 8 output rows (3*gru_a/8 groups):
+ *                                            count, then `count` input positions (multiples of 4)
+ *   gru_a_w          [sparse_nblocks][4][8]  one 8x4 block per idx entry, input-major inside
+ *   gru_b_bias       [2][3*gru_b]      input bias, recurrent bias
+ *   gru_b_w_in       [gru_a][3*gru_b]
+ *   gru_b_w_rec      [gru_b][3*gru_b]
+ *   dual_fc_bias     [2*dual_fc_out]
+ *   dual_fc_w        [dual_fc_out][2][gru_b]     row i: channel-0 weights then channel-1 weights
+ *   dual_fc_factor   [2*dual_fc_out]
+ */
+#ifndef DSS_LPCNET_BLOB_H
+#define DSS_LPCNET_BLOB_H
+
+#include <stdint.h>
+
+#define DSS_BLOB_MAGIC "DSSLPCN1"
+
+typedef struct dss_blob_header {
+    char magic[8];
+    int32_t version;          /* 1 */
+    int32_t nb_features;      /* 20: 18 Bark cepstra + pitch period + pitch correlation */
+    int32_t nb_bands;         /* 18 */
+    int32_t embed_pitch_dim;  /* 64 */
+    int32_t pitch_max;        /* 256 */
+    int32_t conv1_out;        /* 128 */
+    int32_t conv2_out;        /* 128 */
+    int32_t dense1_out;       /* 128 */
+    int32_t dense2_out;       /* 128 */
+    int32_t gru_a;            /* 384 */
+    int32_t gru_b;            /* 16 */
+    int32_t dual_fc_out;      /* 256 */
+    int32_t lpc_order;        /* 16 */
+    int32_t sparse_nblocks;   /* number of 8x4 blocks in gru_a_w */
+    int32_t sparse_idx_len;   /* number of int32 in gru_a_idx */
+    int32_t reserved[7];
+} dss_blob_header;            /* 96 bytes */
+
+#endif

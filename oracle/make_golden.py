@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REFERENCE's own code, run in this container.
+
+Run from the repo root, after `make -C oracle ref`:   python oracle/make_golden.py
+
+What is executed from /root/reference (read-only, never copied):
+  * extensions/hga/hga_optimized.pyx -- compiled as-is into oracle/_ref/ (oracle/Makefile target `ref`);
+    its compute_log_power_features / WarmStartFrameBuffer produce the HGA expected outputs, driven the
+    way HighGammaExtractor.extract_features drives them (local/units.py:145-161: sosfilt x2 with carried
+    state, frame buffer, log power).  local/units.py itself cannot be imported here (zmq, mne, ezmsg,
+    LPCNet are not installed), so that 12-line driver is re-enacted below with scipy.signal.sosfilt.
+  * local/models.py -- imported; BidirectionalSpeechSynthesisModel / UnidirectionalVoiceActivityDetector
+    with torch.manual_seed weights give the decoder expected outputs.
+
+Filter design: the reference calls mne.filter.create_filter(..., method='iir', iir_params={'order': 8,
+'ftype': 'butter'}) (local/units.py:124-126,139-143).  mne is not installed; the coefficients below are
+scipy.signal.iirfilter(8, band/(fs/2), btype, ftype='butter', output='sos'), which is what mne's
+construct_iir_filter resolves that request to.  [UNVERIFIED against mne itself -- recorded in
+tests/golden/README.md]
+
+LPCNet: there is no reference implementation to run (empty submodule), so lpcnet_*.npz fixtures are
+SELF-generated from this repo's oracle (oracle/liboracle.so) and say so in their `provenance` field.
+They pin the oracle against regressions; they do not pin it against xiph.
+"""
+import ctypes
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+sys.path.insert(0, os.path.join(ROOT, "delayed-speech-synthesis_amd"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def design():
+    from scipy.signal import iirfilter, sosfilt_zi
+    fs = 1000
+    hg = iirfilter(8, [70 / (fs / 2), 170 / (fs / 2)], btype="bandpass", ftype="butter", output="sos")
+    fh = iirfilter(8, [118 / (fs / 2), 122 / (fs / 2)], btype="bandstop", ftype="butter", output="sos")
+    return hg, fh, sosfilt_zi(hg), sosfilt_zi(fh)
+
+
+class RefExtractor:
+    """local/units.py:102-161 re-enacted around the reference's compiled Cython module."""
+
+    def __init__(self, fs, C, hg, fh, zi_hg, zi_fh, wl=0.05, ws=0.01):
+        import hga_optimized as ref
+        self.ref = ref
+        self.fs, self.wl, self.ws = fs, wl, ws
+        self.hg, self.fh = hg, fh
+        self.fb = ref.WarmStartFrameBuffer(frame_length=wl, frame_shift=ws, fs=fs, nb_channels=C)
+        # units.py:131-132
+        self.hg_state = np.repeat(zi_hg, C, axis=-1).reshape([zi_hg.shape[0], zi_hg.shape[1], -1])
+        self.fh_state = np.repeat(zi_fh, C, axis=-1).reshape([zi_fh.shape[0], zi_fh.shape[1], -1])
+
+    def extract(self, data):
+        from scipy.signal import sosfilt
+        data, self.hg_state = sosfilt(self.hg, data, axis=0, zi=self.hg_state)
+        data, self.fh_state = sosfilt(self.fh, data, axis=0, zi=self.fh_state)
+        data = self.fb.insert(data)
+        return np.asarray(self.ref.compute_log_power_features(data, self.fs, self.wl, self.ws))
+
+
+def gen_hga():
+    from dss_amd.synthetic import synthetic_ecog
+    hg, fh, zi_hg, zi_fh = design()
+    np.savez(os.path.join(GOLD, "hga_filters.npz"), sos_hg=hg, sos_fh=fh, zi_hg=zi_hg, zi_fh=zi_fh)
+
+    out = {}
+    # (1) small case with the input stored verbatim
+    x = synthetic_ecog(7, 200, 8)
+    out["small_in"] = x
+    out["small_out"] = RefExtractor(1000, 8, hg, fh, zi_hg, zi_fh).extract(x.copy())
+    # (2) offline trials of prepare_corpus.py:47-50 shape: 1.04 s x 64 ch -> 100 frames; seeds 1000..1003
+    for b in range(4):
+        x = synthetic_ecog(1000 + b, 1040, 64)
+        out[f"offline{b}_in_sha"] = np.frombuffer(bytes.fromhex(sha(x)), dtype=np.uint8)
+        out[f"offline{b}_out"] = RefExtractor(1000, 64, hg, fh, zi_hg, zi_fh).extract(x.copy())
+    # (3) online: 40-sample packets (config/debug_settings.ini:21), state carried across packets
+    x = synthetic_ecog(2000, 1040, 64)
+    ex = RefExtractor(1000, 64, hg, fh, zi_hg, zi_fh)
+    frames = [ex.extract(x[i:i + 40].copy()) for i in range(0, 1040, 40)]
+    out["online_counts"] = np.array([len(f) for f in frames], dtype=np.int32)
+    out["online_out"] = np.concatenate(frames, axis=0)
+    # (4) ragged packets (every size > frame shift, as the reference requires, pyx:57), incl. a first
+    #     chunk >= one frame (CASE 1) and an odd channel count
+    sizes = [64, 11, 40, 23, 100, 17, 57, 13, 40]
+    x = synthetic_ecog(2001, sum(sizes), 5)
+    ex = RefExtractor(1000, 5, hg, fh, zi_hg, zi_fh)
+    frames, pos = [], 0
+    for s in sizes:
+        frames.append(ex.extract(x[pos:pos + s].copy()))
+        pos += s
+    out["ragged_sizes"] = np.array(sizes, dtype=np.int32)
+    out["ragged_counts"] = np.array([len(f) for f in frames], dtype=np.int32)
+    out["ragged_out"] = np.concatenate(frames, axis=0)
+    # (5) frame buffer + log power alone on raw (unfiltered) data, three chunk sizes
+    import hga_optimized as ref
+    x = synthetic_ecog(2002, 300, 3)
+    fb = ref.WarmStartFrameBuffer(frame_length=0.05, frame_shift=0.01, fs=1000, nb_channels=3)
+    parts = [np.asarray(ref.compute_log_power_features(np.asarray(fb.insert(x[a:b].copy())), 1000, 0.05, 0.01))
+             for a, b in ((0, 30), (30, 100), (100, 300))]
+    out["rawfb_in"] = x
+    out["rawfb_out"] = np.concatenate(parts, axis=0)
+    np.savez(os.path.join(GOLD, "hga_frames.npz"), **out)
+    print("hga:", {k: v.shape for k, v in out.items() if k.endswith("_out")})
+
+
+def gen_models():
+    import torch
+    sys.path.insert(0, "/root/reference")
+    from local.models import BidirectionalSpeechSynthesisModel, UnidirectionalVoiceActivityDetector
+    out = {}
+    torch.manual_seed(0)
+    m = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64).eval()
+    rng = np.random.default_rng(3000)
+    x = rng.standard_normal((1, 100, 64)).astype(np.float32)
+    with torch.no_grad():
+        y, _ = m(torch.from_numpy(x), m.create_new_initial_state(batch_size=1))
+    out["bilstm_in"] = x
+    out["bilstm_out"] = y.numpy()
+    out["bilstm_params"] = np.array([sum(p.numel() for p in m.parameters())])
+    out["bilstm_sd_sha"] = np.frombuffer(bytes.fromhex(sha(np.concatenate(
+        [v.numpy().ravel() for _, v in sorted(m.state_dict().items())]))), dtype=np.uint8)
+    torch.manual_seed(1)
+    v = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64).eval()
+    with torch.no_grad():
+        s = v.create_new_initial_state(batch_size=1)
+        y1, s = v(torch.from_numpy(x[:, :4]), s)          # streaming: 4 frames per packet, state carried
+        y2, s = v(torch.from_numpy(x[:, 4:8]), s)
+    out["vad_out"] = np.concatenate([y1.numpy(), y2.numpy()], axis=1)
+    out["vad_params"] = np.array([sum(p.numel() for p in v.parameters())])
+    np.savez(os.path.join(GOLD, "models.npz"), **out)
+    print("models:", out["bilstm_out"].shape, out["vad_out"].shape, out["bilstm_params"], out["vad_params"])
+
+
+def gen_lpcnet():
+    from dss_amd.lpcnet_weights import synthetic_blob, synthetic_features
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    lib.oracle_lpcnet_model_load.restype = ctypes.c_void_p
+    lib.oracle_lpcnet_model_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.oracle_lpcnet_synthesize_utterance.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_void_p]
+    blob = synthetic_blob(0)
+    m = lib.oracle_lpcnet_model_load(blob, len(blob))
+    out = {"provenance": np.array("self-generated by oracle/liboracle.so (parity with xiph unpinned)"),
+           "blob_sha": np.frombuffer(hashlib.sha256(blob).digest(), dtype=np.uint8)}
+    for seed, nf in ((0, 100), (1, 100), (2, 30)):
+        f = synthetic_features(seed, nf)
+        pcm = np.zeros(nf * 160, np.int16)
+        lib.oracle_lpcnet_synthesize_utterance(m, f.ctypes.data, nf, 20, pcm.ctypes.data)
+        out[f"utt{seed}_pcm"] = pcm
+        out[f"utt{seed}_feat_sha"] = np.frombuffer(bytes.fromhex(sha(f)), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "lpcnet_self.npz"), **out)
+    print("lpcnet:", {k: v.shape for k, v in out.items() if k.endswith("_pcm")})
+
+
+if __name__ == "__main__":
+    gen_hga()
+    gen_models()
+    gen_lpcnet()
