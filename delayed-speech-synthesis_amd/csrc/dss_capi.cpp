@@ -1,0 +1,741 @@
+// csrc/dss_capi.cpp -- host side of libdss_hip.so: the C ABI declared in include/dss_hip.h.
+//
+// Owns device memory, model upload and launch ordering; all arithmetic of the path runs in the HIP
+// kernels (hga_kernels.hip, lpcnet_frame.hip, lpcnet_sample.hip).  The only numbers produced on the
+// host are constant tables that xiph/LPCNet itself builds at run time with libm (lpcnet_init()'s
+// sampling_logit_table, common.h's ulaw2lin over its 256 integer inputs, freq.c's dct table) and
+// the final log() of dss_hga_log_power / dss_hga_extract's host-buffer form ("HGA log").
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "dss_common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// errors / device
+// ------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void dss_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *dss_last_error(void) { return g_err; }
+
+static thread_local int g_device = -1;
+
+static int ensure_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        dss_set_error("no HIP device available (%s); libdss_hip has no CPU fallback",
+                      e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return DSS_ENODEV;
+    }
+    if (g_device < 0) {
+        const char *lr = getenv("LOCAL_RANK");
+        int d = lr ? atoi(lr) : 0;
+        g_device = (d >= 0 && d < n) ? d : 0;
+    }
+    DSS_HIP_CHECK(hipSetDevice(g_device));
+    return DSS_OK;
+}
+
+extern "C" int dss_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int dss_set_device(int device)
+{
+    int n = dss_device_count();
+    if (device < 0 || device >= n) { dss_set_error("device %d out of range (%d devices)", device, n); return DSS_EINVAL; }
+    g_device = device;
+    DSS_HIP_CHECK(hipSetDevice(device));
+    return DSS_OK;
+}
+
+extern "C" const char *dss_version(void)
+{
+    static char buf[256];
+    hipDeviceProp_t p;
+    int n = dss_device_count();
+    if (n > 0 && hipGetDeviceProperties(&p, g_device < 0 ? 0 : g_device) == hipSuccess)
+        snprintf(buf, sizeof(buf), "libdss_hip 0.1 (gfx950 build) on %s %s, %d CUs", p.name, p.gcnArchName, p.multiProcessorCount);
+    else
+        snprintf(buf, sizeof(buf), "libdss_hip 0.1 (gfx950 build), no device");
+    return buf;
+}
+
+template <typename T>
+static int dev_upload(const T *host, size_t count, T **out)
+{
+    T *d = nullptr;
+    DSS_HIP_CHECK(hipMalloc((void **)&d, count * sizeof(T) + 16));
+    DSS_HIP_CHECK(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return DSS_OK;
+}
+
+template <typename T>
+static int dev_alloc(size_t count, T **out)
+{
+    T *d = nullptr;
+    DSS_HIP_CHECK(hipMalloc((void **)&d, count * sizeof(T) + 16));
+    DSS_HIP_CHECK(hipMemset(d, 0, count * sizeof(T)));
+    *out = d;
+    return DSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// model: blob -> device
+// ------------------------------------------------------------------------------------------------------
+struct HostModel {
+    std::vector<char> blob;
+    dss_blob_header h;
+    double bytes_per_sample = 0;
+    // per-device uploads
+    std::vector<DssModelDev> dev;      // index = device id
+    std::vector<char> dev_ready;
+};
+
+static std::mutex g_model_mu;
+static HostModel *g_model = nullptr;
+
+static float host_ulaw2lin(float u)           // xiph common.h
+{
+    float s;
+    float scale_1 = 32768.f / 255.f;
+    u = u - 128.f;
+    s = (u < 0) ? -1.f : 1.f;
+    u = fabsf(u);
+    return s * scale_1 * (exp(u / 128. * 5.5451774445f) - 1);
+}
+
+struct BlobView {
+    const float *embed_pitch, *conv1_w, *conv1_b, *conv2_w, *conv2_b, *dense1_w, *dense1_b, *dense2_w, *dense2_b;
+    const float *gru_a_dense_w, *gru_a_dense_b, *gru_b_dense_w, *gru_b_dense_b, *embed_sig, *embed_pred, *embed_exc;
+    const float *gru_a_rbias, *gru_a_diag;
+    const int32_t *gru_a_idx;
+    const float *gru_a_w, *gru_b_bias, *gru_b_w_in, *gru_b_w_rec, *fc_bias, *fc_w, *fc_factor;
+};
+
+static int view_blob(const std::vector<char> &blob, const dss_blob_header &h, BlobView &v)
+{
+    const float *p = (const float *)(blob.data() + sizeof(dss_blob_header));
+    const int fin = h.nb_features + h.embed_pitch_dim, NA3 = 3 * h.gru_a, NB3 = 3 * h.gru_b;
+#define TAKE(f, c) do { v.f = p; p += (size_t)(c); } while (0)
+    TAKE(embed_pitch, (size_t)h.pitch_max * h.embed_pitch_dim);
+    TAKE(conv1_w, (size_t)3 * fin * h.conv1_out);          TAKE(conv1_b, h.conv1_out);
+    TAKE(conv2_w, (size_t)3 * h.conv1_out * h.conv2_out);  TAKE(conv2_b, h.conv2_out);
+    TAKE(dense1_w, (size_t)h.conv2_out * h.dense1_out);    TAKE(dense1_b, h.dense1_out);
+    TAKE(dense2_w, (size_t)h.dense1_out * h.dense2_out);   TAKE(dense2_b, h.dense2_out);
+    TAKE(gru_a_dense_w, (size_t)h.dense2_out * NA3);       TAKE(gru_a_dense_b, NA3);
+    TAKE(gru_b_dense_w, (size_t)h.dense2_out * NB3);       TAKE(gru_b_dense_b, NB3);
+    TAKE(embed_sig, (size_t)256 * NA3); TAKE(embed_pred, (size_t)256 * NA3); TAKE(embed_exc, (size_t)256 * NA3);
+    TAKE(gru_a_rbias, NA3); TAKE(gru_a_diag, NA3);
+    v.gru_a_idx = (const int32_t *)p; p += h.sparse_idx_len;
+    TAKE(gru_a_w, (size_t)h.sparse_nblocks * 32);
+    TAKE(gru_b_bias, 2 * NB3); TAKE(gru_b_w_in, (size_t)h.gru_a * NB3); TAKE(gru_b_w_rec, (size_t)h.gru_b * NB3);
+    TAKE(fc_bias, 2 * h.dual_fc_out); TAKE(fc_w, (size_t)h.dual_fc_out * 2 * h.gru_b); TAKE(fc_factor, 2 * h.dual_fc_out);
+#undef TAKE
+    if ((size_t)((const char *)p - blob.data()) != blob.size()) {
+        dss_set_error("weight blob length %zu does not match its header", blob.size());
+        return DSS_EINVAL;
+    }
+    return DSS_OK;
+}
+
+static int check_header(const dss_blob_header &h)
+{
+    if (memcmp(h.magic, DSS_BLOB_MAGIC, 8) != 0 || h.version != 1) { dss_set_error("not a DSSLPCN1 v1 blob"); return DSS_EINVAL; }
+    // the kernels are specialised for the published LPCNet dimensions
+    if (h.nb_features != 20 || h.nb_bands != 18 || h.embed_pitch_dim != 64 || h.pitch_max != 256 || h.conv1_out != 128 ||
+        h.conv2_out != 128 || h.dense1_out != 128 || h.dense2_out != 128 || h.gru_a != DSS_GRU_A || h.gru_b != DSS_GRU_B ||
+        h.dual_fc_out != DSS_FC_OUT || h.lpc_order != DSS_LPC_ORDER) {
+        dss_set_error("blob dimensions differ from the LPCNet architecture this build is specialised for "
+                      "(features 20, conv/dense 128, GRU A 384, GRU B 16, dual FC 256)");
+        return DSS_EINVAL;
+    }
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_load_model(const void *blob, size_t len)
+{
+    if (!blob || len < sizeof(dss_blob_header)) { dss_set_error("blob too short"); return DSS_EINVAL; }
+    HostModel *hm = new HostModel;
+    memcpy(&hm->h, blob, sizeof(hm->h));
+    int rc = check_header(hm->h);
+    if (rc) { delete hm; return rc; }
+    hm->blob.assign((const char *)blob, (const char *)blob + len);
+    BlobView v;
+    rc = view_blob(hm->blob, hm->h, v);
+    if (rc) { delete hm; return rc; }
+    // validate the sparse index (host-side shape check before any kernel trusts it)
+    {
+        const int groups = 3 * hm->h.gru_a / 8;
+        long pos = 0, blocks = 0;
+        for (int g = 0; g < groups; ++g) {
+            if (pos >= hm->h.sparse_idx_len) { dss_set_error("sparse idx truncated"); delete hm; return DSS_EINVAL; }
+            int cnt = v.gru_a_idx[pos++];
+            if (cnt < 0 || pos + cnt > hm->h.sparse_idx_len) { dss_set_error("sparse idx corrupt"); delete hm; return DSS_EINVAL; }
+            for (int j = 0; j < cnt; ++j) {
+                int p = v.gru_a_idx[pos++];
+                if (p < 0 || p + 4 > hm->h.gru_a || (p & 3)) { dss_set_error("sparse idx position %d invalid", p); delete hm; return DSS_EINVAL; }
+            }
+            blocks += cnt;
+        }
+        if (pos != hm->h.sparse_idx_len || blocks != hm->h.sparse_nblocks) { dss_set_error("sparse idx/blocks mismatch"); delete hm; return DSS_EINVAL; }
+    }
+    const int na = hm->h.gru_a, nb = hm->h.gru_b;
+    const double floats = 3.0 * (3 * na) + (double)hm->h.sparse_nblocks * 32 + 3 * na + 3.0 * nb * (na + nb) + 2.0 * nb * 8 + 16;
+    hm->bytes_per_sample = 4.0 * floats + 2.0 + 80.0 / 160.0;
+    std::lock_guard<std::mutex> lk(g_model_mu);
+    g_model = hm;     // earlier models stay alive: states created from them keep their device pointers
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_load_model_file(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { dss_set_error("cannot open %s", path); return DSS_EINVAL; }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)n);
+    size_t got = fread(buf.data(), 1, (size_t)n, f);
+    fclose(f);
+    if (got != (size_t)n) { dss_set_error("short read on %s", path); return DSS_EINVAL; }
+    return dss_lpcnet_load_model(buf.data(), buf.size());
+}
+
+extern "C" double dss_lpcnet_bytes_per_sample(void)
+{
+    std::lock_guard<std::mutex> lk(g_model_mu);
+    return g_model ? g_model->bytes_per_sample : 0.0;
+}
+
+static int upload_model(HostModel *hm, int device, DssModelDev &m)
+{
+    BlobView v;
+    int rc = view_blob(hm->blob, hm->h, v);
+    if (rc) return rc;
+    const dss_blob_header &h = hm->h;
+    memset(&m, 0, sizeof(m));
+    m.h = h;
+    const int fin = h.nb_features + h.embed_pitch_dim, NA = h.gru_a, NA3 = 3 * NA, NB3 = 3 * h.gru_b;
+#define UP(field, src, count) do { float *d; rc = dev_upload<float>(src, (size_t)(count), &d); if (rc) return rc; m.field = d; } while (0)
+    UP(embed_pitch, v.embed_pitch, (size_t)h.pitch_max * h.embed_pitch_dim);
+    UP(conv1_w, v.conv1_w, (size_t)3 * fin * 128);   UP(conv1_b, v.conv1_b, 128);
+    UP(conv2_w, v.conv2_w, (size_t)3 * 128 * 128);   UP(conv2_b, v.conv2_b, 128);
+    UP(dense1_w, v.dense1_w, 128 * 128);             UP(dense1_b, v.dense1_b, 128);
+    UP(dense2_w, v.dense2_w, 128 * 128);             UP(dense2_b, v.dense2_b, 128);
+    UP(gru_a_dense_w, v.gru_a_dense_w, (size_t)128 * NA3);  UP(gru_a_dense_b, v.gru_a_dense_b, NA3);
+    UP(gru_b_dense_w, v.gru_b_dense_w, (size_t)128 * NB3);  UP(gru_b_dense_b, v.gru_b_dense_b, NB3);
+    UP(embed_sig, v.embed_sig, (size_t)256 * NA3);
+    UP(embed_pred, v.embed_pred, (size_t)256 * NA3);
+    UP(embed_exc, v.embed_exc, (size_t)256 * NA3);
+    UP(gru_a_rbias, v.gru_a_rbias, NA3);
+    UP(gru_a_diag, v.gru_a_diag, NA3);
+    UP(gru_b_bias, v.gru_b_bias, 2 * NB3);
+    UP(gru_b_w_in, v.gru_b_w_in, (size_t)NA * NB3);
+    UP(gru_b_w_rec, v.gru_b_w_rec, (size_t)h.gru_b * NB3);
+    UP(fc_bias, v.fc_bias, 2 * h.dual_fc_out);
+    UP(fc_w, v.fc_w, (size_t)h.dual_fc_out * 2 * h.gru_b);
+    UP(fc_factor, v.fc_factor, 2 * h.dual_fc_out);
+
+    // ---- sparse GRU A: per gate, per unit, a padded list of (pos, 4 weights) slots in idx order ----------
+    {
+        const int groups_per_gate = NA / 8;
+        std::vector<int> grp_start(3 * groups_per_gate), grp_cnt(3 * groups_per_gate), grp_blk(3 * groups_per_gate);
+        long pos = 0, blk = 0;
+        for (int g = 0; g < 3 * groups_per_gate; ++g) {
+            grp_cnt[g] = v.gru_a_idx[pos];
+            grp_start[g] = (int)pos + 1;
+            grp_blk[g] = (int)blk;
+            pos += 1 + grp_cnt[g];
+            blk += grp_cnt[g];
+        }
+        for (int gate = 0; gate < 3; ++gate) {
+            int slots = 0;
+            for (int g = 0; g < groups_per_gate; ++g) slots = std::max(slots, grp_cnt[gate * groups_per_gate + g]);
+            std::vector<int> pos4((size_t)std::max(slots, 1) * NA, 0);
+            std::vector<float> w((size_t)std::max(slots, 1) * 4 * NA, 0.f);
+            for (int unit = 0; unit < NA; ++unit) {
+                const int g = gate * groups_per_gate + unit / 8, r = unit & 7;
+                for (int sl = 0; sl < grp_cnt[g]; ++sl) {
+                    pos4[(size_t)sl * NA + unit] = v.gru_a_idx[grp_start[g] + sl] * 4;
+                    const float *wb = v.gru_a_w + (size_t)(grp_blk[g] + sl) * 32;
+                    for (int k = 0; k < 4; ++k) w[((size_t)sl * 4 + k) * NA + unit] = wb[k * 8 + r];
+                }
+            }
+            int *dpos; float *dw;
+            rc = dev_upload<int>(pos4.data(), pos4.size(), &dpos); if (rc) return rc;
+            rc = dev_upload<float>(w.data(), w.size(), &dw); if (rc) return rc;
+            m.gate[gate].slots = slots; m.gate[gate].pos4 = dpos; m.gate[gate].w = dw;
+        }
+    }
+    // ---- derived tables (host libm, exactly as xiph builds them at run time) ---------------------------
+    {
+        float tansig[201], logit[256], u2l[256], dct[18 * 18], costab[320], ia[160], ib[160];
+        int iband[160];
+        double lagw[17];
+        for (int i = 0; i < 201; ++i) tansig[i] = (float)(floor(tanh(.04 * i) * 1e6 + .5) / 1e6);   // tansig_table.h
+        for (int i = 0; i < 256; ++i) {                                                              // lpcnet_init()
+            float prob = .025 + .95 * i / 255.;
+            logit[i] = -log((1 - prob) / prob);
+            u2l[i] = host_ulaw2lin((float)i);
+        }
+        for (int i = 0; i < 18; ++i)                                                                  // freq.c check_init()
+            for (int j = 0; j < 18; ++j) {
+                dct[i * 18 + j] = cos((i + .5) * j * M_PI / 18);
+                if (j == 0) dct[i * 18 + j] *= sqrt(.5);
+            }
+        for (int i = 0; i < 320; ++i) costab[i] = (float)cos(2. * M_PI * i / 320);
+        static const int eband5ms[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40};
+        for (int i = 0; i < 17; ++i) {                                                                // interp_band_gain()
+            const int band_size = (eband5ms[i + 1] - eband5ms[i]) * 4;
+            for (int j = 0; j < band_size; ++j) {
+                const float frac = (float)j / band_size;
+                ia[eband5ms[i] * 4 + j] = 1 - frac;
+                ib[eband5ms[i] * 4 + j] = frac;
+                iband[eband5ms[i] * 4 + j] = i;
+            }
+        }
+        for (int i = 0; i < 17; ++i) lagw[i] = (1 - 6e-5 * i * i);
+        float *d; int *di; double *dd;
+        rc = dev_upload<float>(tansig, 201, &d); if (rc) return rc; m.tansig = d;
+        rc = dev_upload<float>(logit, 256, &d); if (rc) return rc; m.logit_table = d;
+        rc = dev_upload<float>(u2l, 256, &d); if (rc) return rc; m.ulaw2lin = d;
+        rc = dev_upload<float>(dct, 324, &d); if (rc) return rc; m.dct_table = d;
+        rc = dev_upload<float>(costab, 320, &d); if (rc) return rc; m.cos_table = d;
+        rc = dev_upload<float>(ia, 160, &d); if (rc) return rc; m.interp_a = d;
+        rc = dev_upload<float>(ib, 160, &d); if (rc) return rc; m.interp_b = d;
+        rc = dev_upload<int>(iband, 160, &di); if (rc) return rc; m.interp_band = di;
+        rc = dev_upload<double>(lagw, 17, &dd); if (rc) return rc; m.lag_window = dd;
+    }
+#undef UP
+    (void)device;
+    return DSS_OK;
+}
+
+static int get_model(HostModel **out_hm, const DssModelDev **out)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_model_mu);
+    if (!g_model) {
+        const char *path = getenv("DSS_LPCNET_WEIGHTS");
+        if (!path) { dss_set_error("no LPCNet weights: call dss_lpcnet_load_model() or set DSS_LPCNET_WEIGHTS"); return DSS_ENOMODEL; }
+        g_model_mu.unlock();
+        rc = dss_lpcnet_load_model_file(path);
+        g_model_mu.lock();
+        if (rc) return rc;
+    }
+    HostModel *hm = g_model;
+    const int ndev = dss_device_count();
+    if ((int)hm->dev.size() < ndev) { hm->dev.resize(ndev); hm->dev_ready.resize(ndev, 0); }
+    if (!hm->dev_ready[g_device]) {
+        rc = upload_model(hm, g_device, hm->dev[g_device]);
+        if (rc) return rc;
+        hm->dev_ready[g_device] = 1;
+    }
+    *out_hm = hm;
+    *out = &hm->dev[g_device];
+    return DSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// batched decoder
+// ------------------------------------------------------------------------------------------------------
+struct dss_lpcnet_batch {
+    int device;
+    const DssModelDev *model;
+    DssBatchDev d;
+    int last_utts = 0, last_frames = 0;
+    int trace = 0, timing = 0;
+    float *d_feat = nullptr;      // staging for the host-buffer entry point
+    short *d_pcm = nullptr;
+    hipEvent_t ev[3];
+    double ms_sum[2] = {0, 0};
+    int ms_n = 0;
+};
+
+extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frames)
+{
+    if (max_utts <= 0 || max_frames <= 0) { dss_set_error("batch dims must be positive"); return nullptr; }
+    HostModel *hm; const DssModelDev *m;
+    if (get_model(&hm, &m)) return nullptr;
+    dss_lpcnet_batch *b = new dss_lpcnet_batch;
+    memset(&b->d, 0, sizeof(b->d));
+    b->device = g_device;
+    b->model = m;
+    DssBatchDev &d = b->d;
+    d.max_utts = max_utts; d.max_frames = max_frames;
+    const size_t B = max_utts, F = max_frames;
+    int rc = 0;
+    rc |= dev_alloc<float>(B * DSS_GRU_A, &d.gru_a_state);
+    rc |= dev_alloc<float>(B * DSS_GRU_B, &d.gru_b_state);
+    rc |= dev_alloc<float>(B * 16, &d.last_sig);
+    rc |= dev_alloc<int>(B, &d.last_exc);
+    rc |= dev_alloc<float>(B, &d.deemph);
+    rc |= dev_alloc<uint32_t>(B * 4, &d.rng);
+    rc |= dev_alloc<int>(B, &d.frame_count);
+    rc |= dev_alloc<float>(B * 2 * 84, &d.conv1_mem);
+    rc |= dev_alloc<float>(B * 2 * 128, &d.conv2_mem);
+    rc |= dev_alloc<float>(B * 2 * 16, &d.old_lpc);
+    rc |= dev_alloc<float>(B * (F + 2) * 84, &d.in_buf);
+    rc |= dev_alloc<float>(B * (F + 2) * 128, &d.c1_buf);
+    rc |= dev_alloc<float>(B * F * 128, &d.c2_buf);
+    rc |= dev_alloc<float>(B * F * 128, &d.d1_buf);
+    rc |= dev_alloc<float>(B * F * 128, &d.cond_buf);
+    rc |= dev_alloc<float>(B * (F + 2) * 16, &d.lpc_buf);
+    rc |= dev_alloc<float>(B * F * DSS_COND_STRIDE, &d.frame_out);
+    rc |= dev_alloc<int>(B, &d.fc0);
+    rc |= dev_alloc<float>(B * F * 20, &b->d_feat);
+    rc |= dev_alloc<short>(B * F * DSS_FRAME_SIZE, &b->d_pcm);
+    for (int i = 0; i < 3; ++i) rc |= (hipEventCreate(&b->ev[i]) != hipSuccess);
+    if (rc) { dss_set_error("device allocation failed for batch %d x %d", max_utts, max_frames); delete b; return nullptr; }
+    if (dss_launch_lpcnet_reset(*m, d, -1, 0) || hipDeviceSynchronize() != hipSuccess) { delete b; return nullptr; }
+    return b;
+}
+
+extern "C" void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b)
+{
+    if (!b) return;
+    hipSetDevice(b->device);
+    DssBatchDev &d = b->d;
+    void *ptrs[] = {d.gru_a_state, d.gru_b_state, d.last_sig, d.last_exc, d.deemph, d.rng, d.frame_count, d.conv1_mem,
+                    d.conv2_mem, d.old_lpc, d.in_buf, d.c1_buf, d.c2_buf, d.d1_buf, d.cond_buf, d.lpc_buf, d.frame_out,
+                    d.fc0, d.trace_exc, d.trace_pcm, b->d_feat, b->d_pcm};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (int i = 0; i < 3; ++i) hipEventDestroy(b->ev[i]);
+    delete b;
+}
+
+extern "C" int dss_lpcnet_batch_reset(dss_lpcnet_batch *b, int utt)
+{
+    if (!b || utt >= b->d.max_utts) { dss_set_error("bad batch/utt"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    int rc = dss_launch_lpcnet_reset(*b->model, b->d, utt, 0);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipStreamSynchronize(0));
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_batch_enable_trace(dss_lpcnet_batch *b, int on)
+{
+    if (!b) return DSS_EINVAL;
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    if (on && !b->d.trace_exc) {
+        const size_t n = (size_t)b->d.max_utts * b->d.max_frames * DSS_FRAME_SIZE;
+        int rc = dev_alloc<float>(n, &b->d.trace_exc);
+        rc |= dev_alloc<float>(n, &b->d.trace_pcm);
+        if (rc) return DSS_ENOMEM;
+    }
+    b->trace = on ? 1 : 0;
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_batch_enable_timing(dss_lpcnet_batch *b, int on)
+{
+    if (!b) return DSS_EINVAL;
+    b->timing = on ? 1 : 0;
+    b->ms_sum[0] = b->ms_sum[1] = 0; b->ms_n = 0;
+    return DSS_OK;
+}
+
+extern "C" double dss_lpcnet_batch_kernel_ms(dss_lpcnet_batch *b, int which)
+{
+    if (!b || b->ms_n == 0 || which < 0 || which > 1) return 0.0;
+    double v = b->ms_sum[which] / b->ms_n;
+    if (which == 0) { /* keep accumulating until both have been read */ }
+    return v;
+}
+
+extern "C" int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float *d_features, int n_utts, int n_frames,
+                                               int feat_stride, short *d_pcm, void *hip_stream)
+{
+    if (!b || !d_features || !d_pcm) { dss_set_error("null argument"); return DSS_EINVAL; }
+    if (n_utts <= 0 || n_utts > b->d.max_utts || n_frames <= 0 || n_frames > b->d.max_frames || feat_stride < DSS_NB_FEATURES) {
+        dss_set_error("shape out of range: %d utts (max %d), %d frames (max %d), stride %d", n_utts, b->d.max_utts, n_frames,
+                      b->d.max_frames, feat_stride);
+        return DSS_EINVAL;
+    }
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (b->timing) DSS_HIP_CHECK(hipEventRecord(b->ev[0], s));
+    int rc = dss_launch_frame_network(*b->model, b->d, d_features, n_utts, n_frames, feat_stride, s);
+    if (rc) return rc;
+    if (b->timing) DSS_HIP_CHECK(hipEventRecord(b->ev[1], s));
+    rc = dss_launch_sample_network(*b->model, b->d, n_utts, n_frames, d_pcm, b->trace, s);
+    if (rc) return rc;
+    if (b->timing) {
+        DSS_HIP_CHECK(hipEventRecord(b->ev[2], s));
+        DSS_HIP_CHECK(hipEventSynchronize(b->ev[2]));
+        float fr = 0, sm = 0;
+        DSS_HIP_CHECK(hipEventElapsedTime(&fr, b->ev[0], b->ev[1]));
+        DSS_HIP_CHECK(hipEventElapsedTime(&sm, b->ev[1], b->ev[2]));
+        b->ms_sum[0] += sm; b->ms_sum[1] += fr; b->ms_n += 1;
+    }
+    b->last_utts = n_utts; b->last_frames = n_frames;
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_batch_synthesize(dss_lpcnet_batch *b, const float *features, int n_utts, int n_frames,
+                                           int feat_stride, short *pcm)
+{
+    if (!b || !features || !pcm) { dss_set_error("null argument"); return DSS_EINVAL; }
+    if (n_utts <= 0 || n_utts > b->d.max_utts || n_frames <= 0 || n_frames > b->d.max_frames || feat_stride < DSS_NB_FEATURES) {
+        dss_set_error("shape out of range: %d utts (max %d), %d frames (max %d), stride %d", n_utts, b->d.max_utts, n_frames,
+                      b->d.max_frames, feat_stride);
+        return DSS_EINVAL;
+    }
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    // pack the first 20 floats of every row (feature files carry 36, LPCNet.pyx:97,115)
+    DSS_HIP_CHECK(hipMemcpy2D(b->d_feat, DSS_NB_FEATURES * sizeof(float), features, (size_t)feat_stride * sizeof(float),
+                              DSS_NB_FEATURES * sizeof(float), (size_t)n_utts * n_frames, hipMemcpyHostToDevice));
+    int rc = dss_lpcnet_batch_synthesize_dev(b, b->d_feat, n_utts, n_frames, DSS_NB_FEATURES, b->d_pcm, nullptr);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipMemcpy(pcm, b->d_pcm, (size_t)n_utts * n_frames * DSS_FRAME_SIZE * sizeof(short), hipMemcpyDeviceToHost));
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_batch_tap(dss_lpcnet_batch *b, int utt, int which, float *out, size_t n_floats)
+{
+    if (!b || !out || utt < 0 || utt >= b->last_utts) { dss_set_error("bad tap arguments"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    DSS_HIP_CHECK(hipDeviceSynchronize());
+    const int F = b->last_frames;
+    if (which >= 0 && which <= 2) {
+        const int width = which == 0 ? 3 * DSS_GRU_A : which == 1 ? 3 * DSS_GRU_B : DSS_LPC_ORDER;
+        const int off = which == 0 ? 0 : which == 1 ? 3 * DSS_GRU_A : 3 * DSS_GRU_A + 3 * DSS_GRU_B;
+        if (n_floats < (size_t)F * width) { dss_set_error("tap buffer too small"); return DSS_EINVAL; }
+        DSS_HIP_CHECK(hipMemcpy2D(out, width * sizeof(float), b->d.frame_out + (size_t)utt * F * DSS_COND_STRIDE + off,
+                                  DSS_COND_STRIDE * sizeof(float), width * sizeof(float), F, hipMemcpyDeviceToHost));
+        return DSS_OK;
+    }
+    if ((which == 3 || which == 4) && b->d.trace_exc) {
+        const size_t n = (size_t)F * DSS_FRAME_SIZE;
+        if (n_floats < n) { dss_set_error("tap buffer too small"); return DSS_EINVAL; }
+        const float *src = (which == 3 ? b->d.trace_exc : b->d.trace_pcm) + (size_t)utt * n;
+        DSS_HIP_CHECK(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+        return DSS_OK;
+    }
+    dss_set_error("unknown tap %d (or trace not enabled)", which);
+    return DSS_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// xiph drop-in symbols: one state = a batch of one utterance, one frame per call
+// ------------------------------------------------------------------------------------------------------
+struct LPCNetState { dss_lpcnet_batch *b; };
+
+extern "C" LPCNetState *lpcnet_create(void)
+{
+    dss_lpcnet_batch *b = dss_lpcnet_batch_create(1, 1);
+    if (!b) return nullptr;
+    LPCNetState *st = new LPCNetState;
+    st->b = b;
+    return st;
+}
+
+extern "C" int lpcnet_init(LPCNetState *st)
+{
+    if (!st) return -1;
+    return dss_lpcnet_batch_reset(st->b, -1);
+}
+
+extern "C" void lpcnet_destroy(LPCNetState *st)
+{
+    if (!st) return;
+    dss_lpcnet_batch_destroy(st->b);
+    delete st;
+}
+
+extern "C" void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N)
+{
+    if (!st || !features || !output) return;
+    if (N != DSS_FRAME_SIZE) {           // the reference only ever asks for one 160-sample frame (LPCNet.pyx:39)
+        dss_set_error("lpcnet_synthesize: N must be %d, got %d", DSS_FRAME_SIZE, N);
+        fprintf(stderr, "libdss_hip: %s\n", g_err);
+        abort();
+    }
+    if (dss_lpcnet_batch_synthesize(st->b, features, 1, 1, DSS_NB_FEATURES, output)) {
+        fprintf(stderr, "libdss_hip: lpcnet_synthesize failed: %s\n", g_err);   // void in the xiph ABI: fail loudly
+        abort();
+    }
+}
+
+extern "C" int lpcnet_get_size(void) { return (int)sizeof(LPCNetState); }
+
+// ------------------------------------------------------------------------------------------------------
+// HGA
+// ------------------------------------------------------------------------------------------------------
+extern "C" int dss_hga_num_windows(int T, int sr, float window_length, float window_shift)
+{
+    // hga_optimized.pyx:36 -- float32 products, C floor()
+    return (int)floor((T - window_length * sr) / (window_shift * sr)) + 1;
+}
+
+extern "C" int dss_hga_log_power(const double *data, int T, int C, int sr, float wl, float ws, double *out)
+{
+    if (!data || !out || T <= 0 || C <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int W = dss_hga_num_windows(T, sr, wl, ws);
+    if (W <= 0) return DSS_OK;
+    double *d_in = nullptr, *d_out = nullptr;
+    DSS_HIP_CHECK(hipMalloc((void **)&d_in, sizeof(double) * (size_t)T * C));
+    DSS_HIP_CHECK(hipMalloc((void **)&d_out, sizeof(double) * (size_t)W * C));
+    DSS_HIP_CHECK(hipMemcpy(d_in, data, sizeof(double) * (size_t)T * C, hipMemcpyHostToDevice));
+    rc = dss_launch_log_power(d_in, T, C, sr, wl, ws, W, d_out, 0, 0);
+    if (!rc) {
+        hipError_t e = hipMemcpy(out, d_out, sizeof(double) * (size_t)W * C, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { dss_set_error("copy back failed: %s", hipGetErrorString(e)); rc = DSS_ENODEV; }
+    }
+    hipFree(d_in); hipFree(d_out);
+    if (rc) return rc;
+    for (size_t k = 0; k < (size_t)W * C; ++k) out[k] = log(out[k]);       // pyx:46, host libm (DESIGN.md "HGA log")
+    return DSS_OK;
+}
+
+struct dss_hga {
+    int device;
+    DssHgaDev d;
+    int first_frame = 1;
+    double *d_zi0[2] = {nullptr, nullptr};
+    double *d_in = nullptr, *d_out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+};
+
+static int hga_grow_rows(dss_hga *h, int need_rows)
+{
+    if (need_rows <= h->d.cap_rows) return DSS_OK;
+    const int new_cap = need_rows + h->d.frame_length;
+    double *nr = nullptr;
+    DSS_HIP_CHECK(hipMalloc((void **)&nr, sizeof(double) * (size_t)h->d.S * new_cap * h->d.C));
+    if (h->d.rows) {
+        DSS_HIP_CHECK(hipMemcpy2D(nr, sizeof(double) * (size_t)new_cap * h->d.C, h->d.rows,
+                                  sizeof(double) * (size_t)h->d.cap_rows * h->d.C,
+                                  sizeof(double) * (size_t)h->d.overlap * h->d.C, h->d.S, hipMemcpyDeviceToDevice));
+        hipFree(h->d.rows);
+    }
+    h->d.rows = nr;
+    h->d.cap_rows = new_cap;
+    return DSS_OK;
+}
+
+extern "C" dss_hga *dss_hga_create(int n_streams, int n_channels, int fs, float window_length, float window_shift,
+                                   int n_sections, const double *sos_hg, const double *sos_fh, const double *zi_hg,
+                                   const double *zi_fh)
+{
+    if (n_streams <= 0 || n_channels <= 0 || n_sections <= 0 || n_sections > 8 || !sos_hg || !sos_fh || !zi_hg || !zi_fh) {
+        dss_set_error("bad HGA arguments (1..8 second-order sections supported)");
+        return nullptr;
+    }
+    if (ensure_device()) return nullptr;
+    dss_hga *h = new dss_hga;
+    h->device = g_device;
+    DssHgaDev &d = h->d;
+    memset(&d, 0, sizeof(d));
+    d.S = n_streams; d.C = n_channels; d.fs = fs; d.nsec = n_sections; d.wl = window_length; d.ws = window_shift;
+    // hga_optimized.pyx:72-74 (float32 products truncated to int)
+    const int shift = (int)(window_shift * fs);
+    d.frame_length = (int)(window_length * fs);
+    d.overlap = d.frame_length - shift;
+    for (int q = 0; q < n_sections; ++q)
+        for (int k = 0; k < 6; ++k) { d.sos[0][q][k] = sos_hg[q * 6 + k]; d.sos[1][q][k] = sos_fh[q * 6 + k]; }
+    int rc = dev_alloc<double>((size_t)n_streams * 2 * 8 * 2 * n_channels, &d.zi);
+    rc |= dev_upload<double>(zi_hg, (size_t)n_sections * 2, &h->d_zi0[0]);
+    rc |= dev_upload<double>(zi_fh, (size_t)n_sections * 2, &h->d_zi0[1]);
+    if (!rc) rc = hga_grow_rows(h, d.overlap + 4 * d.frame_length);
+    if (!rc) rc = dss_launch_hga_reset(d, h->d_zi0[0], h->d_zi0[1], 0);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = DSS_ENODEV;
+    if (rc) { dss_set_error("HGA device setup failed"); delete h; return nullptr; }
+    return h;
+}
+
+extern "C" void dss_hga_destroy(dss_hga *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    void *ptrs[] = {h->d.zi, h->d.rows, h->d_zi0[0], h->d_zi0[1], h->d_in, h->d_out};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete h;
+}
+
+extern "C" int dss_hga_reset(dss_hga *h)
+{
+    if (!h) return DSS_EINVAL;
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    int rc = dss_launch_hga_reset(h->d, h->d_zi0[0], h->d_zi0[1], 0);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipStreamSynchronize(0));
+    h->first_frame = 1;
+    return DSS_OK;
+}
+
+// rows the frame buffer hands to the window stage for n new samples, and where the new rows start
+static void hga_plan(const dss_hga *h, int n, int *row0, int *zero_rows, int *rows)
+{
+    const int fl = h->d.frame_length, ov = h->d.overlap;
+    if (h->first_frame && n >= fl) { *row0 = 0; *zero_rows = 0; *rows = n; }                      // CASE 1, pyx:104-107
+    else if (h->first_frame) { *row0 = fl - n; *zero_rows = fl - n; *rows = fl; }                  // CASE 2, pyx:111-122
+    else { *row0 = ov; *zero_rows = 0; *rows = ov + n; }                                           // CASE 3, pyx:123-131
+}
+
+extern "C" int dss_hga_frames_for(const dss_hga *h, int n)
+{
+    if (!h || n <= 0) return 0;
+    int row0, zr, rows;
+    hga_plan(h, n, &row0, &zr, &rows);
+    int W = dss_hga_num_windows(rows, h->d.fs, h->d.wl, h->d.ws);
+    return W < 0 ? 0 : W;
+}
+
+extern "C" int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, int apply_log, void *hip_stream)
+{
+    if (!h || !d_data || !d_out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    int row0, zr, rows;
+    hga_plan(h, n, &row0, &zr, &rows);
+    int rc = hga_grow_rows(h, rows);
+    if (rc) return rc;
+    int W = dss_hga_num_windows(rows, h->d.fs, h->d.wl, h->d.ws);
+    if (W < 0) W = 0;
+    rc = dss_launch_hga(h->d, d_data, n, row0, zr, rows, W, d_out, apply_log, (hipStream_t)hip_stream);
+    if (rc) return rc;
+    h->first_frame = 0;
+    return W;
+}
+
+extern "C" int dss_hga_extract(dss_hga *h, const double *data, int n, double *out)
+{
+    if (!h || !data || !out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    const size_t in_n = (size_t)h->d.S * n * h->d.C;
+    const int Wmax = dss_hga_frames_for(h, n);
+    const size_t out_n = (size_t)h->d.S * (Wmax > 0 ? Wmax : 1) * h->d.C;
+    if (in_n > h->in_cap) { if (h->d_in) hipFree(h->d_in); DSS_HIP_CHECK(hipMalloc((void **)&h->d_in, in_n * sizeof(double))); h->in_cap = in_n; }
+    if (out_n > h->out_cap) { if (h->d_out) hipFree(h->d_out); DSS_HIP_CHECK(hipMalloc((void **)&h->d_out, out_n * sizeof(double))); h->out_cap = out_n; }
+    DSS_HIP_CHECK(hipMemcpy(h->d_in, data, in_n * sizeof(double), hipMemcpyHostToDevice));
+    const int W = dss_hga_extract_dev(h, h->d_in, n, h->d_out, 0, nullptr);
+    if (W < 0) return W;
+    if (W == 0) { DSS_HIP_CHECK(hipDeviceSynchronize()); return 0; }
+    const size_t cnt = (size_t)h->d.S * W * h->d.C;
+    DSS_HIP_CHECK(hipMemcpy(out, h->d_out, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < cnt; ++k) out[k] = log(out[k]);                 // pyx:46, host libm (DESIGN.md "HGA log")
+    return W;
+}

@@ -1,0 +1,112 @@
+// csrc/dss_common.h -- shared host/device declarations of libdss_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/dss_hip.h"
+#include "../../include/dss_lpcnet_blob.h"
+
+// ---- fixed architecture constants of the path (checked against the blob at load) ----
+#define DSS_NB_FEATURES 20
+#define DSS_NB_BANDS 18
+#define DSS_LPC_ORDER 16
+#define DSS_FRAME_SIZE 160
+#define DSS_GRU_A 384
+#define DSS_GRU_B 16
+#define DSS_FC_OUT 256
+#define DSS_COND_STRIDE (3 * DSS_GRU_A + 3 * DSS_GRU_B + DSS_LPC_ORDER)   // 1216 floats per frame
+#define DSS_FEATURES_DELAY 2
+
+void dss_set_error(const char *fmt, ...);
+
+#define DSS_HIP_CHECK(expr)                                                                        \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            dss_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DSS_ENODEV;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+// ---- device-resident model (built once per loaded blob, per device) ---------------------------------
+struct DssSparseGate {
+    int slots;            // padded number of 8x4 blocks per unit for this gate
+    const int *pos4;      // [slots][384]  byte offset (pos * 4) of the block's first input in the state vector
+    const float *w;       // [slots][4][384]
+};
+
+struct DssModelDev {
+    dss_blob_header h;
+    // frame-rate network (input-major dense matrices, as in the blob)
+    const float *embed_pitch, *conv1_w, *conv1_b, *conv2_w, *conv2_b, *dense1_w, *dense1_b, *dense2_w, *dense2_b;
+    const float *gru_a_dense_w, *gru_a_dense_b, *gru_b_dense_w, *gru_b_dense_b;
+    // sample-rate network
+    const float *embed_sig, *embed_pred, *embed_exc;        // [256][1152]
+    const float *gru_a_rbias, *gru_a_diag;                  // [1152]
+    DssSparseGate gate[3];
+    const float *gru_b_bias;                                // [2][48]
+    const float *gru_b_w_in;                                // [384][48]
+    const float *gru_b_w_rec;                               // [16][48]
+    const float *fc_bias, *fc_w, *fc_factor;                // [512], [256][2][16], [512]
+    // derived tables (host libm, see dss_capi.cpp)
+    const float *tansig;          // [201]
+    const float *logit_table;     // [256]
+    const float *ulaw2lin;        // [256]
+    const float *dct_table;       // [18*18]
+    const float *cos_table;       // [320]
+    const float *interp_a, *interp_b;   // [160] (1-frac), frac of interp_band_gain
+    const int *interp_band;       // [160] band index i of each bin
+    const double *lag_window;     // [17] 1 - 6e-5*i*i
+};
+
+// ---- per-batch device state ---------------------------------------------------------------------------
+struct DssBatchDev {
+    int max_utts, max_frames;
+    // decoder state, one row per utterance
+    float *gru_a_state;   // [B][384]
+    float *gru_b_state;   // [B][16]
+    float *last_sig;      // [B][16]
+    int *last_exc;        // [B]
+    float *deemph;        // [B]
+    uint32_t *rng;        // [B][4]
+    int *frame_count;     // [B]
+    float *conv1_mem;     // [B][2][84]
+    float *conv2_mem;     // [B][2][128]
+    float *old_lpc;       // [B][2][16]   row 0 = older (old_lpc[1]), row 1 = newer (old_lpc[0])
+    // per-call scratch of the frame-rate network
+    float *in_buf;        // [B][F+2][84]
+    float *c1_buf;        // [B][F+2][128]
+    float *c2_buf;        // [B][F][128]
+    float *d1_buf;        // [B][F][128]
+    float *cond_buf;      // [B][F][128]
+    float *lpc_buf;       // [B][F+2][16]
+    float *frame_out;     // [B][F][DSS_COND_STRIDE]  gru_a_condition | gru_b_condition | lpc
+    int *fc0;             // [B] frame_count at the start of the call
+    // trace (optional)
+    float *trace_exc, *trace_pcm;   // [B][F*160]
+};
+
+// kernels (defined in the .hip files)
+int dss_launch_frame_network(const DssModelDev &m, DssBatchDev &b, const float *d_features, int n_utts, int n_frames,
+                             int feat_stride, hipStream_t s);
+int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
+                              int trace, hipStream_t s);
+int dss_launch_lpcnet_reset(const DssModelDev &m, DssBatchDev &b, int utt, hipStream_t s);
+
+struct DssHgaDev {
+    int S, C, fs, nsec;
+    float wl, ws;
+    int frame_length, overlap, cap_rows;
+    double *zi;        // [S][2][8][2][C]
+    double *rows;      // [S][cap_rows][C]
+    double sos[2][8][6];
+};
+int dss_launch_hga(const DssHgaDev &h, const double *d_data, int n, int row0, int zero_rows, int rows, int W,
+                   double *d_out, int apply_log, hipStream_t s);
+int dss_launch_hga_reset(const DssHgaDev &h, const double *d_zi_hg, const double *d_zi_fh, hipStream_t s);
+int dss_launch_log_power(const double *d_data, int T, int C, int sr, float wl, float ws, int W, double *d_out,
+                         int apply_log, hipStream_t s);

@@ -1,0 +1,69 @@
+// csrc/lpcnet_device.h -- device-side scalar helpers of the LPCNet kernels.
+//
+// Each helper restates one inline function of xiph/LPCNet (src/vec.h generic path, src/common.h) in the
+// exact operation order and precision of the C source: float where the C is float, double where C's
+// usual arithmetic conversions promote to double.  The library is built with -ffp-contract=off so no
+// product/sum pair is fused.  Tables (tansig, ulaw2lin, sampling logits) are computed by the host's
+// libm when a model is loaded and passed in; the device never evaluates exp/log/tanh on this path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// vec.h tanh_approx (201-entry table form).  `tab` may live in LDS or global memory.
+__device__ __forceinline__ float dss_tanh_approx(const float *tab, float x)
+{
+    float sign = 1.f;
+    if (x < 0) { x = -x; sign = -1.f; }
+    int i = (int)floorf(.5f + 25 * x);
+    i = i < 0 ? 0 : i;
+    i = i > 200 ? 200 : i;
+    x -= .04f * i;
+    const float y = tab[i];
+    const float dy = 1 - y * y;
+    const float r = y + x * dy * (1 - y * x);
+    return sign * r;
+}
+
+__device__ __forceinline__ float dss_sigmoid_approx(const float *tab, float x)
+{
+    return .5f + .5f * dss_tanh_approx(tab, .5f * x);
+}
+
+// common.h log2_approx / lin2ulaw
+__device__ __forceinline__ float dss_log2_approx(float x)
+{
+    int in = __float_as_int(x);
+    const int integer = (in >> 23) - 127;
+    in -= integer << 23;
+    float frac = __int_as_float(in) - 1.5f;
+    frac = -0.41445418f + frac * (0.95909232f + frac * (-0.33951290f + frac * 0.16541097f));
+    return 1 + integer + frac;
+}
+
+__device__ __forceinline__ int dss_lin2ulaw(float x)
+{
+    const float scale = 255.f / 32768.f;
+    const int s = (x < 0) ? -1 : 1;
+    x = fabsf(x);
+    float u = (s * (128 * (0.69315f * dss_log2_approx(1 + scale * x)) / 5.5451774445f));
+    u = 128 + u;
+    if (u < 0) u = 0;
+    if (u > 255) u = 255;
+    return (int)floor(.5 + (double)u);
+}
+
+// kiss99.c
+struct DssKiss99 { uint32_t z, w, jsr, jcong; };
+
+__device__ __forceinline__ uint32_t dss_kiss99_rand(DssKiss99 &c)
+{
+    const uint32_t znew = 36969u * (c.z & 0xFFFF) + (c.z >> 16);
+    const uint32_t wnew = 18000u * (c.w & 0xFFFF) + (c.w >> 16);
+    const uint32_t mwc = (znew << 16) + wnew;
+    uint32_t shr3 = c.jsr ^ (c.jsr << 17);
+    shr3 ^= shr3 >> 13;
+    shr3 ^= shr3 << 5;
+    const uint32_t cong = 69069u * c.jcong + 1234567u;
+    c.z = znew; c.w = wnew; c.jsr = shr3; c.jcong = cong;
+    return (mwc ^ cong) + shr3;
+}

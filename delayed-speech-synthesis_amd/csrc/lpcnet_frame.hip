@@ -1,0 +1,244 @@
+// csrc/lpcnet_frame.hip -- LPCNet frame-rate network for a batch of utterances (gfx950).
+//
+// Restates xiph/LPCNet src/lpcnet.c run_frame_network() as consumed through lpcnet_synthesize()
+// (reference binding: extensions/lpcnet/cLPCNet.pxd:13; callers local/units.py:535, local/training.py:194):
+//   pitch embedding -> conv1d(k=3) tanh -> conv1d(k=3) tanh -> dense tanh -> dense tanh
+//   -> {gru_a_dense_feature, gru_b_dense_feature} (linear), and lpc_from_cepstrum with the 2-frame delay.
+//
+// In batch mode all frames' features are known up front, and the only temporal coupling is the two
+// previous inputs of each conv (plus the saved conv memories / old_lpc of the persistent state), so
+// every layer runs as one launch over all (utterance, frame) rows.  A row's dot products are
+// accumulated one product at a time in ascending input order (xiph sgemv_accum: out[i] += w[j][i]*x[j]),
+// one lane per output neuron, so results are bit-identical to the scalar C path.  Weights are input-major
+// so a wave reads 256 contiguous bytes per input; a block reuses each weight across RT rows staged in LDS.
+#include "dss_common.h"
+#include "lpcnet_device.h"
+
+#define FIN (DSS_NB_FEATURES + 64)    // 84: features + pitch embedding
+
+// ---- stage 0: build the padded per-utterance input rows and snapshot frame_count -----------------------
+// in_buf[b][0..1] = conv1_mem, in_buf[b][t+2] = [features(20) | embed_pitch(64)]
+// c1_buf[b][0..1] = conv2_mem, lpc_buf[b][0..1] = old_lpc
+__global__ void __launch_bounds__(128)
+frame_prepare_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, int n_frames, int feat_stride)
+{
+    const int utt = blockIdx.y, row = blockIdx.x, tid = threadIdx.x;      // row in [0, F+2)
+    float *in = b.in_buf + ((size_t)utt * (n_frames + 2) + row) * FIN;
+    if (row < 2) {
+        if (tid < FIN) in[tid] = b.conv1_mem[((size_t)utt * 2 + row) * FIN + tid];
+        b.c1_buf[((size_t)utt * (n_frames + 2) + row) * 128 + tid] = b.conv2_mem[((size_t)utt * 2 + row) * 128 + tid];
+        if (tid < 16) b.lpc_buf[((size_t)utt * (n_frames + 2) + row) * 16 + tid] = b.old_lpc[((size_t)utt * 2 + row) * 16 + tid];
+        if (row == 0 && tid == 0) b.fc0[utt] = b.frame_count[utt];
+        return;
+    }
+    const float *f = feat + ((size_t)utt * n_frames + (row - 2)) * feat_stride;
+    if (tid < DSS_NB_FEATURES) {
+        in[tid] = f[tid];
+    } else if (tid < FIN) {
+        // lpcnet.c: pitch = (int)floor(.1 + 50*features[NB_BANDS]+100), clamped to [33, 255]
+        int pitch = (int)floor(.1 + (double)(50 * f[DSS_NB_BANDS]) + 100);
+        pitch = pitch < 33 ? 33 : pitch;
+        pitch = pitch > 255 ? 255 : pitch;
+        in[tid] = m.embed_pitch[(size_t)pitch * 64 + (tid - DSS_NB_FEATURES)];
+    }
+}
+
+// ---- generic dense layer over rows ----------------------------------------------------------------------
+enum { ACT_LINEAR = 0, ACT_TANH = 1 };
+
+template <int ACT, int RT>
+__global__ void __launch_bounds__(128)
+dense_rows_kernel(const float *__restrict__ x, long x_utt_stride, int x_row_stride,
+                  const float *__restrict__ W, const float *__restrict__ bias, int M, int N,
+                  float *__restrict__ out, long out_utt_stride, int out_row_stride, int out_col_off,
+                  int rows_per_utt, int total_rows, int zero_below, const int *__restrict__ fc0,
+                  const float *__restrict__ tansig)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [RT][M]
+    const int tid = threadIdx.x;
+    const int i = blockIdx.y * 128 + tid;
+    const int r0 = blockIdx.x * RT;
+    for (int rr = 0; rr < RT; ++rr) {
+        const int r = r0 + rr;
+        if (r < total_rows) {
+            const int ub = r / rows_per_utt, t = r - ub * rows_per_utt;
+            const float *src = x + (size_t)ub * x_utt_stride + (size_t)t * x_row_stride;
+            for (int j = tid; j < M; j += 128) xs[rr * M + j] = src[j];
+        } else {
+            for (int j = tid; j < M; j += 128) xs[rr * M + j] = 0.f;
+        }
+    }
+    __syncthreads();
+    if (i >= N) return;
+    float acc[RT];
+    const float bi = bias[i];
+#pragma unroll
+    for (int rr = 0; rr < RT; ++rr) acc[rr] = bi;
+    for (int j = 0; j < M; j += 4) {
+        const float w0 = W[(size_t)(j + 0) * N + i];
+        const float w1 = W[(size_t)(j + 1) * N + i];
+        const float w2 = W[(size_t)(j + 2) * N + i];
+        const float w3 = W[(size_t)(j + 3) * N + i];
+#pragma unroll
+        for (int rr = 0; rr < RT; ++rr) {
+            const float4 xv = *reinterpret_cast<const float4 *>(&xs[rr * M + j]);
+            acc[rr] += w0 * xv.x;
+            acc[rr] += w1 * xv.y;
+            acc[rr] += w2 * xv.z;
+            acc[rr] += w3 * xv.w;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RT; ++rr) {
+        const int r = r0 + rr;
+        if (r < total_rows) {
+            const int ub = r / rows_per_utt, t = r - ub * rows_per_utt;
+            float v = acc[rr];
+            if (ACT == ACT_TANH) v = dss_tanh_approx(tansig, v);
+            if (zero_below > 0 && fc0[ub] + t < zero_below) v = 0.f;   // lpcnet.c: RNN_CLEAR while frame_count < delay
+            out[(size_t)ub * out_utt_stride + (size_t)t * out_row_stride + out_col_off + i] = v;
+        }
+    }
+}
+
+// ---- lpc_from_cepstrum (freq.c) for every (utterance, frame): one wave per frame ------------------------
+__constant__ float c_compensation[DSS_NB_BANDS] = {0.8f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.666667f, 0.5f, 0.5f, 0.5f,
+                                                   0.333333f, 0.25f, 0.25f, 0.2f, 0.166667f, 0.173913f};
+
+__global__ void __launch_bounds__(64)
+frame_lpc_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, int n_frames, int feat_stride,
+                 double idct_scale)
+{
+    __shared__ float Ex[DSS_NB_BANDS];
+    __shared__ float Xr[161];
+    __shared__ float ac[DSS_LPC_ORDER + 1];
+    const int utt = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+    const float *cep = feat + ((size_t)utt * n_frames + t) * feat_stride;
+    if (lane < DSS_NB_BANDS) {
+        float sum = 0;
+        for (int j = 0; j < DSS_NB_BANDS; ++j) {
+            float c = cep[j];
+            if (j == 0) c += 4;
+            sum += c * m.dct_table[lane * DSS_NB_BANDS + j];
+        }
+        const float e = (float)((double)sum * idct_scale);                 // sum*sqrt(2./NB_BANDS)
+        Ex[lane] = (float)(pow(10.0, (double)e) * (double)c_compensation[lane]);
+    }
+    __syncthreads();
+    for (int k = lane; k < 160; k += 64) {                                  // interp_band_gain
+        const int band = m.interp_band[k];
+        Xr[k] = m.interp_a[k] * Ex[band] + m.interp_b[k] * Ex[band + 1];
+    }
+    if (lane == 0) Xr[160] = 0.f;
+    __syncthreads();
+    if (lane <= DSS_LPC_ORDER) {                                            // direct inverse DFT, 17 lags
+        float acc = Xr[0];
+        int idx = 0;
+        for (int k = 1; k < 160; ++k) {
+            idx += lane;
+            if (idx >= 320) idx -= 320;
+            acc += (2.f * Xr[k]) * m.cos_table[idx];
+        }
+        ac[lane] = acc;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float a[DSS_LPC_ORDER + 1];
+        for (int i = 0; i <= DSS_LPC_ORDER; ++i) a[i] = ac[i];
+        a[0] = (float)((double)a[0] + ((double)a[0] * 1e-4 + 320 / 12 / 38.));
+        for (int i = 1; i <= DSS_LPC_ORDER; ++i) a[i] = (float)((double)a[i] * m.lag_window[i]);
+        float lpc[DSS_LPC_ORDER];
+        for (int i = 0; i < DSS_LPC_ORDER; ++i) lpc[i] = 0.f;
+        float error = a[0];
+        if (a[0] != 0) {
+            for (int i = 0; i < DSS_LPC_ORDER; i++) {
+                float rr = 0;
+                for (int j = 0; j < i; j++) rr += lpc[j] * a[i - j];
+                rr += a[i + 1];
+                const float r = -rr / error;
+                lpc[i] = r;
+                for (int j = 0; j < (i + 1) >> 1; j++) {
+                    const float tmp1 = lpc[j], tmp2 = lpc[i - 1 - j];
+                    lpc[j] = tmp1 + r * tmp2;
+                    lpc[i - 1 - j] = tmp2 + r * tmp1;
+                }
+                error = error - (r * r) * error;
+                if (error < .001f * a[0]) break;
+            }
+        }
+        float *dst = b.lpc_buf + ((size_t)utt * (n_frames + 2) + t + 2) * 16;
+        for (int i = 0; i < DSS_LPC_ORDER; ++i) dst[i] = lpc[i];
+    }
+}
+
+// ---- final stage: delayed lpc into frame_out, persistent state update ------------------------------------
+__global__ void __launch_bounds__(128)
+frame_finish_kernel(DssBatchDev b, int n_frames)
+{
+    const int utt = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    if (t < n_frames) {
+        if (tid < 16)
+            b.frame_out[((size_t)utt * n_frames + t) * DSS_COND_STRIDE + 3 * DSS_GRU_A + 3 * DSS_GRU_B + tid] =
+                b.lpc_buf[((size_t)utt * (n_frames + 2) + t) * 16 + tid];       // lpc of frame t-2 (old_lpc chain)
+        return;
+    }
+    // t == n_frames: one block per utterance updates the carried state
+    for (int row = 0; row < 2; ++row) {
+        const size_t src = (size_t)utt * (n_frames + 2) + n_frames + row;
+        if (tid < FIN) b.conv1_mem[((size_t)utt * 2 + row) * FIN + tid] = b.in_buf[src * FIN + tid];
+        b.conv2_mem[((size_t)utt * 2 + row) * 128 + tid] = b.c1_buf[src * 128 + tid];
+        if (tid < 16) b.old_lpc[((size_t)utt * 2 + row) * 16 + tid] = b.lpc_buf[src * 16 + tid];
+    }
+    if (tid == 0) {
+        int fc = b.fc0[utt] + n_frames;
+        b.frame_count[utt] = fc > 1000 ? 1000 : fc;
+    }
+}
+
+template <int ACT>
+static int launch_dense(const float *x, long xus, int xrs, const float *W, const float *bias, int M, int N, float *out,
+                        long ous, int ors, int ooff, int rows_per_utt, int total_rows, int zero_below, const int *fc0,
+                        const float *tansig, hipStream_t s)
+{
+    constexpr int RT = 8;
+    dim3 grid((total_rows + RT - 1) / RT, (N + 127) / 128);
+    const size_t lds = (size_t)RT * M * sizeof(float);
+    hipLaunchKernelGGL((dense_rows_kernel<ACT, RT>), grid, dim3(128), lds, s, x, xus, xrs, W, bias, M, N, out, ous, ors, ooff,
+                       rows_per_utt, total_rows, zero_below, fc0, tansig);
+    DSS_HIP_CHECK(hipGetLastError());
+    return DSS_OK;
+}
+
+int dss_launch_frame_network(const DssModelDev &m, DssBatchDev &b, const float *d_features, int B, int F, int feat_stride,
+                             hipStream_t s)
+{
+    const int rows = B * F;
+    hipLaunchKernelGGL(frame_prepare_kernel, dim3(F + 2, B), dim3(128), 0, s, m, b, d_features, F, feat_stride);
+    DSS_HIP_CHECK(hipGetLastError());
+    int rc;
+    // conv1: window of 3 input rows (t, t+1, t+2 of the padded buffer) -> c1_buf[b][t+2]
+    rc = launch_dense<ACT_TANH>(b.in_buf, (long)(F + 2) * FIN, FIN, m.conv1_w, m.conv1_b, 3 * FIN, 128, b.c1_buf + 2 * 128,
+                                (long)(F + 2) * 128, 128, 0, F, rows, 1, b.fc0, m.tansig, s);
+    if (rc) return rc;
+    rc = launch_dense<ACT_TANH>(b.c1_buf, (long)(F + 2) * 128, 128, m.conv2_w, m.conv2_b, 3 * 128, 128, b.c2_buf,
+                                (long)F * 128, 128, 0, F, rows, 2, b.fc0, m.tansig, s);
+    if (rc) return rc;
+    rc = launch_dense<ACT_TANH>(b.c2_buf, (long)F * 128, 128, m.dense1_w, m.dense1_b, 128, 128, b.d1_buf, (long)F * 128,
+                                128, 0, F, rows, 0, b.fc0, m.tansig, s);
+    if (rc) return rc;
+    rc = launch_dense<ACT_TANH>(b.d1_buf, (long)F * 128, 128, m.dense2_w, m.dense2_b, 128, 128, b.cond_buf, (long)F * 128,
+                                128, 0, F, rows, 0, b.fc0, m.tansig, s);
+    if (rc) return rc;
+    rc = launch_dense<ACT_LINEAR>(b.cond_buf, (long)F * 128, 128, m.gru_a_dense_w, m.gru_a_dense_b, 128, 3 * DSS_GRU_A,
+                                  b.frame_out, (long)F * DSS_COND_STRIDE, DSS_COND_STRIDE, 0, F, rows, 0, b.fc0, m.tansig, s);
+    if (rc) return rc;
+    rc = launch_dense<ACT_LINEAR>(b.cond_buf, (long)F * 128, 128, m.gru_b_dense_w, m.gru_b_dense_b, 128, 3 * DSS_GRU_B,
+                                  b.frame_out, (long)F * DSS_COND_STRIDE, DSS_COND_STRIDE, 3 * DSS_GRU_A, F, rows, 0, b.fc0,
+                                  m.tansig, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(frame_lpc_kernel, dim3(F, B), dim3(64), 0, s, m, b, d_features, F, feat_stride, sqrt(2. / DSS_NB_BANDS));
+    DSS_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(frame_finish_kernel, dim3(F + 1, B), dim3(128), 0, s, b, F);
+    DSS_HIP_CHECK(hipGetLastError());
+    return DSS_OK;
+}

@@ -1,0 +1,97 @@
+"""High-gamma feature extraction on MI355X: Python host side of Part 3 of include/dss_hip.h."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+def design_filters(fs: int = 1000, l_freq: float = 70, h_freq: float = 170, order: int = 8):
+    """The two SOS cascades HighGammaExtractor builds (local/units.py:124-126): Butterworth band-pass
+    l_freq..h_freq and band-stop 118..122 Hz.  The reference asks mne.filter.create_filter(method='iir',
+    iir_params={'order': 8, 'ftype': 'butter'}); mne resolves that to scipy.signal.iirfilter(order, Wn,
+    btype, ftype='butter', output='sos'), which is called directly here (mne is not a dependency)."""
+    from scipy.signal import iirfilter, sosfilt_zi
+    nyq = fs / 2.0
+    hg = iirfilter(order, [l_freq / nyq, h_freq / nyq], btype="bandpass", ftype="butter", output="sos")
+    fh = iirfilter(order, [118 / nyq, 122 / nyq], btype="bandstop", ftype="butter", output="sos")
+    return hg, fh, sosfilt_zi(hg), sosfilt_zi(fh)
+
+
+def num_windows(T: int, sr: int, wl: float, ws: float) -> int:
+    return int(_lib.load().dss_hga_num_windows(int(T), int(sr), wl, ws))
+
+
+def log_power(data: np.ndarray, sr: int, wl: float, ws: float) -> np.ndarray:
+    """compute_log_power_features (hga_optimized.pyx:27-47) on the GPU; float64 (T, C) -> (W, C)."""
+    L = _lib.require_gpu()
+    d = np.ascontiguousarray(data, dtype=np.float64)
+    if d.ndim != 2:
+        raise ValueError("Buffer has wrong number of dimensions (expected 2, got %d)" % d.ndim)
+    W = max(num_windows(d.shape[0], sr, wl, ws), 0)
+    out = np.empty((W, d.shape[1]), dtype=np.float64)
+    if W:
+        _lib.check(L.dss_hga_log_power(d.ctypes.data, d.shape[0], d.shape[1], int(sr), wl, ws, out.ctypes.data))
+    return out
+
+
+class HgaExtractorGPU:
+    """n_streams independent HighGammaExtractor states (filter state + warm-start frame buffer) on one GPU."""
+
+    def __init__(self, n_streams: int, n_channels: int, fs: int = 1000, window_length: float = 0.05,
+                 window_shift: float = 0.01, filters=None):
+        L = _lib.require_gpu()
+        self._L = L
+        hg, fh, zi_hg, zi_fh = filters if filters is not None else design_filters(fs)
+        hg, fh = (np.ascontiguousarray(a, dtype=np.float64) for a in (hg, fh))
+        zi_hg, zi_fh = (np.ascontiguousarray(a, dtype=np.float64) for a in (zi_hg, zi_fh))
+        if hg.shape != fh.shape or hg.shape[1] != 6:
+            raise ValueError("both filters must be (n_sections, 6) SOS arrays of equal length")
+        self.S, self.C, self.fs = int(n_streams), int(n_channels), int(fs)
+        self.wl, self.ws = float(window_length), float(window_shift)
+        self._h = L.dss_hga_create(self.S, self.C, self.fs, self.wl, self.ws, hg.shape[0], hg.ctypes.data,
+                                   fh.ctypes.data, zi_hg.ctypes.data, zi_fh.ctypes.data)
+        if not self._h:
+            raise _lib.DssError(L.dss_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dss_hga_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        _lib.check(self._L.dss_hga_reset(self._h))
+
+    def frames_for(self, n: int) -> int:
+        return int(self._L.dss_hga_frames_for(self._h, int(n)))
+
+    def extract(self, data: np.ndarray) -> np.ndarray:
+        """(S, n, C) float64 host -> (S, W, C) float64 host, bit-identical to the reference chain."""
+        d = np.ascontiguousarray(data, dtype=np.float64)
+        if d.ndim == 2:
+            d = d[None]
+        if d.shape[0] != self.S or d.shape[2] != self.C:
+            raise ValueError(f"expected ({self.S}, n, {self.C}), got {d.shape}")
+        n = d.shape[1]
+        W = self.frames_for(n)
+        out = np.empty((self.S, max(W, 1), self.C), dtype=np.float64)
+        got = _lib.check(self._L.dss_hga_extract(self._h, d.ctypes.data, n, out.ctypes.data))
+        assert got == W
+        return out[:, :W].reshape(self.S, W, self.C) if W else np.empty((self.S, 0, self.C))
+
+    def extract_torch(self, data, apply_log: bool = True, out=None, stream=None):
+        """Device-resident: (S, n, C) float64 CUDA tensor -> (S, W, C) float64 CUDA tensor."""
+        import torch
+        assert data.is_cuda and data.dtype == torch.float64 and data.is_contiguous()
+        n = data.shape[1]
+        W = self.frames_for(n)
+        if out is None:
+            out = torch.empty((self.S, W, self.C), dtype=torch.float64, device=data.device)
+        s = torch.cuda.current_stream(data.device).cuda_stream if stream is None else stream
+        got = _lib.check(self._L.dss_hga_extract_dev(self._h, data.data_ptr(), n, out.data_ptr(), int(apply_log), s))
+        assert got == W
+        return out

@@ -1,0 +1,140 @@
+/*
+ * include/dss_hip.h -- C ABI of libdss_hip.so, the MI355X (gfx950) hot path of
+ * cronelab/delayed-speech-synthesis: LPCNet vocoder + high-gamma (HGA) feature extractor.
+ *
+ * Plain C, plain pointers and sizes; no torch / C++ types.  Every entry point names the reference
+ * interface it replaces (file:line relative to the reference repository).
+ *
+ * Part 1 is a drop-in for the four xiph/LPCNet decoder symbols the reference's Cython wrapper binds
+ * (extensions/lpcnet/cLPCNet.pxd:10-13): the reference's own LPCNet.pyx can be compiled against this
+ * header + library unchanged (INTEGRATION.md shows how).
+ * Part 2 is the batched form of the same operator (what AsynchronousSynthesisQueue's process pool,
+ * local/training.py:165-207, and the north-star batch configs need).
+ * Part 3 is the HGA operator (extensions/hga/hga_optimized.pyx and HighGammaExtractor,
+ * local/units.py:97-161).
+ *
+ * Error convention: functions returning int return 0 on success and a negative DSS_E* code on failure;
+ * dss_last_error() gives a thread-local message.  Creators return NULL on failure (the reference's
+ * wrapper turns NULL into MemoryError, LPCNet.pyx:16-17).  There is NO CPU fallback: without a HIP
+ * device every compute entry point fails with DSS_ENODEV.
+ *
+ * Threading (same contract as the reference): one state is used by one thread at a time;
+ * different states may be used from different threads.  Do not fork() after the first call.
+ */
+#ifndef DSS_HIP_H
+#define DSS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSS_OK        0
+#define DSS_EINVAL   -1   /* bad argument / shape */
+#define DSS_ENODEV   -2   /* no HIP device, or HIP runtime error (see dss_last_error) */
+#define DSS_ENOMODEL -3   /* no LPCNet weight blob loaded */
+#define DSS_ENOMEM   -4
+
+const char *dss_last_error(void);
+/* Library version and the device it runs on ("gfx950 ..."); never NULL. */
+const char *dss_version(void);
+int dss_device_count(void);
+/* Select the HIP device used by objects created afterwards on this thread (default 0 / LOCAL_RANK). */
+int dss_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 1 -- xiph LPCNet decoder symbols, as bound by extensions/lpcnet/cLPCNet.pxd:10-13
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct LPCNetState LPCNetState;
+
+/* cLPCNet.pxd:10.  Allocates one decoder state (device resident) bound to the process-wide model.
+ * The model is the blob given to dss_lpcnet_load_model*, else the file named by $DSS_LPCNET_WEIGHTS.
+ * NULL if neither exists or no device is available. */
+LPCNetState *lpcnet_create(void);
+/* cLPCNet.pxd:11.  Zeroes the state, last_exc = ulaw(0), RNG re-seeded with "LPCNet". Returns 0. */
+int lpcnet_init(LPCNetState *st);
+/* cLPCNet.pxd:12 */
+void lpcnet_destroy(LPCNetState *st);
+/* cLPCNet.pxd:13.  One 10 ms frame: features[0..19] (host) -> output[0..N-1] (host), N must be 160
+ * (LPCNet.pyx:10,39).  Runs the frame-rate network once, then N autoregressive sample steps. */
+void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N);
+/* xiph lpcnet.h: size of the opaque state (reported for completeness; states live on the device). */
+int lpcnet_get_size(void);
+
+/* Weights are data in this build (include/dss_lpcnet_blob.h); xiph compiles them in (nnet_data.c,
+ * extensions/lpcnet/setup.py:34-36). */
+int dss_lpcnet_load_model(const void *blob, size_t len);
+int dss_lpcnet_load_model_file(const char *path);
+/* SURVEY.md 8(d) algorithmic bytes per output sample for the loaded model (0 if none). */
+double dss_lpcnet_bytes_per_sample(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 2 -- batched decoder: B independent utterances / streams, one persistent workgroup each.
+ * Replaces the one-process-per-file pool of local/training.py:165-207 and the per-row Python loop of
+ * DelayedLPCNetVocoder.synthesize (local/units.py:531-538).  State persists across calls exactly like
+ * a vector of LPCNetState (so it also serves 128 concurrent streams, 1 frame per call).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dss_lpcnet_batch dss_lpcnet_batch;
+
+dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frames);
+void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b);
+/* lpcnet_init() on every slot (or on slot `utt` only when utt >= 0). */
+int dss_lpcnet_batch_reset(dss_lpcnet_batch *b, int utt);
+/* Host buffers.  features: [n_utts][n_frames][feat_stride] float32 (feat_stride >= 20, first 20 used,
+ * e.g. 36 for xiph .f32 feature files, LPCNet.pyx:97,115).  pcm: [n_utts][n_frames*160] int16. */
+int dss_lpcnet_batch_synthesize(dss_lpcnet_batch *b, const float *features, int n_utts, int n_frames,
+                                int feat_stride, short *pcm);
+/* Device buffers (same shapes), asynchronous on `hip_stream` (a hipStream_t, or NULL for the default
+ * stream).  Nothing is copied to or from the host. */
+int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float *d_features, int n_utts, int n_frames,
+                                    int feat_stride, short *d_pcm, void *hip_stream);
+/* Test taps (device -> host): frame-rate network outputs of the LAST call, per utterance and frame:
+ * which = 0: gru_a_condition [n_frames][3*gru_a]; 1: gru_b_condition [n_frames][3*gru_b]; 2: lpc [n_frames][16].
+ * which = 3: per-sample excitation index (uint8 stored as float) [n_frames*160]; 4: pre-de-emphasis pcm float.
+ * (3 and 4 need dss_lpcnet_batch_enable_trace(b, 1) before the call.) */
+int dss_lpcnet_batch_tap(dss_lpcnet_batch *b, int utt, int which, float *out, size_t n_floats);
+int dss_lpcnet_batch_enable_trace(dss_lpcnet_batch *b, int on);
+/* Average device time (ms) of the sample-rate kernel over the calls since the last query, measured with
+ * HIP events on the stream the kernel was launched on; resets the accumulator.  Needs
+ * dss_lpcnet_batch_enable_timing(b, 1). */
+int dss_lpcnet_batch_enable_timing(dss_lpcnet_batch *b, int on);
+double dss_lpcnet_batch_kernel_ms(dss_lpcnet_batch *b, int which /*0 = sample kernel, 1 = frame kernels*/);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 3 -- HGA: IIR cascade + warm-start frame buffer + log power, float64
+ * ---------------------------------------------------------------------------------------------- */
+/* compute_log_power_features(data, sr, window_length, window_shift)  hga_optimized.pyx:27-47.
+ * data: host (T, C) float64 row-major.  out: host (W, C), W = dss_hga_num_windows(T, ...).
+ * Windowed mean power runs on the device; the final log() is applied by the host libm while copying
+ * out, which is what makes the result bit-identical to the reference on any host. */
+int dss_hga_num_windows(int T, int sr, float window_length, float window_shift);
+int dss_hga_log_power(const double *data, int T, int C, int sr, float window_length, float window_shift,
+                      double *out);
+
+/* Stateful extractor for n_streams independent streams of n_channels each: the GPU counterpart of
+ * HighGammaExtractor (local/units.py:97-161) without the Python pre/post transforms.
+ * sos_hg / sos_fh: (n_sections, 6) band-pass and band-stop second-order sections (units.py:124-126);
+ * zi_hg / zi_fh: (n_sections, 2) scipy.signal.sosfilt_zi(sos), replicated over channels as
+ * units.py:128-132 does.  Holds per-channel filter state and the last `overlap` filtered rows
+ * (WarmStartFrameBuffer, hga_optimized.pyx:50-131) on the device. */
+typedef struct dss_hga dss_hga;
+dss_hga *dss_hga_create(int n_streams, int n_channels, int fs, float window_length, float window_shift,
+                        int n_sections, const double *sos_hg, const double *sos_fh,
+                        const double *zi_hg, const double *zi_fh);
+void dss_hga_destroy(dss_hga *h);
+int dss_hga_reset(dss_hga *h);
+/* Frames the next extract call with n new samples per stream will emit. */
+int dss_hga_frames_for(const dss_hga *h, int n);
+/* extract_features (units.py:145-161): data host (n_streams, n, C) float64 -> out host (n_streams, W, C).
+ * Returns W (>= 0) or a negative error.  All streams advance by the same n. */
+int dss_hga_extract(dss_hga *h, const double *data, int n, double *out);
+/* Device-resident form: d_data / d_out device pointers; log applied on the device (OCML log, <= 1 ulp
+ * from the host's) when apply_log != 0, else out = mean power + 0.01. */
+int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, int apply_log, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSS_HIP_H */
