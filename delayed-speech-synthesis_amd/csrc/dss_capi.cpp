@@ -434,6 +434,13 @@ extern "C" int dss_lpcnet_batch_reset(dss_lpcnet_batch *b, int utt)
     return DSS_OK;
 }
 
+extern "C" int dss_lpcnet_batch_reset_async(dss_lpcnet_batch *b, int utt, void *hip_stream)
+{
+    if (!b || utt >= b->d.max_utts) { dss_set_error("bad batch/utt"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    return dss_launch_lpcnet_reset(*b->model, b->d, utt, (hipStream_t)hip_stream);
+}
+
 extern "C" int dss_lpcnet_batch_enable_trace(dss_lpcnet_batch *b, int on)
 {
     if (!b) return DSS_EINVAL;

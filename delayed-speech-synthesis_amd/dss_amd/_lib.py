@@ -37,6 +37,7 @@ def _declare(L):
         "dss_lpcnet_batch_create": (vp, [i, i]),
         "dss_lpcnet_batch_destroy": (None, [vp]),
         "dss_lpcnet_batch_reset": (i, [vp, i]),
+        "dss_lpcnet_batch_reset_async": (i, [vp, i, vp]),
         "dss_lpcnet_batch_synthesize": (i, [vp, vp, i, i, i, vp]),
         "dss_lpcnet_batch_synthesize_dev": (i, [vp, vp, i, i, i, vp, vp]),
         "dss_lpcnet_batch_tap": (i, [vp, i, i, vp, sz]),

@@ -70,6 +70,11 @@ class LPCNetBatch:
     def reset(self, utt: int = -1):
         _lib.check(self._L.dss_lpcnet_batch_reset(self._h, int(utt)))
 
+    def reset_async(self, utt: int = -1, stream=None):
+        import torch
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _lib.check(self._L.dss_lpcnet_batch_reset_async(self._h, int(utt), s))
+
     def synthesize(self, features: np.ndarray) -> np.ndarray:
         """features (B, F, >=20) float32 host array -> (B, F*160) int16.  State carries to the next call."""
         f = np.ascontiguousarray(features, dtype=np.float32)

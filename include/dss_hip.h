@@ -82,6 +82,8 @@ dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frames);
 void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b);
 /* lpcnet_init() on every slot (or on slot `utt` only when utt >= 0). */
 int dss_lpcnet_batch_reset(dss_lpcnet_batch *b, int utt);
+/* Same, enqueued on `hip_stream` without waiting (for device-resident pipelines and timed loops). */
+int dss_lpcnet_batch_reset_async(dss_lpcnet_batch *b, int utt, void *hip_stream);
 /* Host buffers.  features: [n_utts][n_frames][feat_stride] float32 (feat_stride >= 20, first 20 used,
  * e.g. 36 for xiph .f32 feature files, LPCNet.pyx:97,115).  pcm: [n_utts][n_frames*160] int16. */
 int dss_lpcnet_batch_synthesize(dss_lpcnet_batch *b, const float *features, int n_utts, int n_frames,
