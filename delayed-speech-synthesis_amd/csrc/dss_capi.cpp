@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -286,6 +287,77 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
             m.gate[gate].slots = slots; m.gate[gate].pos4 = dpos; m.gate[gate].w = dw;
         }
     }
+    // ---- CU-resident layout of the sample-rate kernel (lpcnet_sample.hip) ---------------------------------
+    {
+        const int G = NA / 8;                       // 48 row groups per gate
+        std::vector<int> cnt(3 * G), start(3 * G), blk0(3 * G);
+        long pos = 0, blk = 0;
+        for (int g = 0; g < 3 * G; ++g) {
+            cnt[g] = v.gru_a_idx[pos]; start[g] = (int)pos + 1; blk0[g] = (int)blk;
+            pos += 1 + cnt[g]; blk += cnt[g];
+        }
+        int fast_ok = (NA == 384 && G == 48);
+        int zmax = 0, hmax = 0;
+        for (int g = 0; g < G; ++g) {
+            zmax = std::max(zmax, std::max(cnt[g], cnt[G + g]));
+            hmax = std::max(hmax, cnt[2 * G + g]);
+        }
+        if (zmax > DSS_ZRC || hmax > DSS_HC) fast_ok = 0;
+        // row groups sorted by h-gate block count: 8 consecutive groups share a wave, so each wave's h-gate
+        // loop length (its largest group) is close to what every group in it needs
+        std::vector<int> order(G);
+        for (int g = 0; g < G; ++g) order[g] = g;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return cnt[2 * G + a] > cnt[2 * G + b2]; });
+        std::vector<int> unit_of(NA, 0), wave_nh(8, 0), wave_hoff(8, 0);
+        int hfloats = 0;
+        for (int wv = 0; wv < 6 && fast_ok; ++wv) {
+            int nh = 0;
+            for (int q = 0; q < 8; ++q) nh = std::max(nh, cnt[2 * G + order[wv * 8 + q]]);
+            nh = (nh + 1) & ~1;                     // the kernel tests for the end of the list every 2 slots
+            wave_nh[wv] = nh; wave_hoff[wv] = hfloats;
+            hfloats += 8 * nh * 32;
+        }
+        if ((size_t)hfloats * sizeof(float) > DSS_HBLK_BYTES) fast_ok = 0;
+        std::vector<float> zr_w((size_t)2 * DSS_ZRC * 4 * NA, 0.f), hblk((size_t)std::max(hfloats, 4), 0.f);
+        std::vector<unsigned> zr_col((size_t)(2 * DSS_ZRC / 4) * NA, 0u), h_col((size_t)(DSS_HC / 4) * NA, 0u);
+        if (fast_ok)
+            for (int tid = 0; tid < NA; ++tid) {
+                const int wv = tid / 64, l = tid & 63, q = l / 8, r = l & 7, grp = order[wv * 8 + q];
+                unit_of[tid] = grp * 8 + r;
+                for (int gate = 0; gate < 2; ++gate) {
+                    const int g = gate * G + grp;
+                    for (int sl = 0; sl < cnt[g]; ++sl) {
+                        const int s2 = gate * DSS_ZRC + sl;
+                        const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                        for (int k = 0; k < 4; ++k) zr_w[((size_t)s2 * 4 + k) * NA + tid] = wb[k * 8 + r];
+                        zr_col[(size_t)(s2 >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (s2 & 3));
+                    }
+                }
+                const int g = 2 * G + grp;
+                for (int sl = 0; sl < cnt[g]; ++sl) {
+                    const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                    float *rec = hblk.data() + wave_hoff[wv] + ((size_t)q * wave_nh[wv] + sl) * 32 + r * 4;
+                    for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
+                    h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
+                }
+            }
+        m.fast_ok = fast_ok;
+        m.nzr_max = (zmax + 1) & ~1;
+        m.hblk_floats = hfloats;
+        int *di; float *df; unsigned *du;
+        rc = dev_upload<int>(unit_of.data(), unit_of.size(), &di); if (rc) return rc; m.unit_of = di;
+        rc = dev_upload<int>(wave_nh.data(), wave_nh.size(), &di); if (rc) return rc; m.wave_nh = di;
+        rc = dev_upload<int>(wave_hoff.data(), wave_hoff.size(), &di); if (rc) return rc; m.wave_hoff = di;
+        rc = dev_upload<float>(zr_w.data(), zr_w.size(), &df); if (rc) return rc; m.zr_w = df;
+        rc = dev_upload<unsigned>(zr_col.data(), zr_col.size(), &du); if (rc) return rc; m.zr_col = du;
+        rc = dev_upload<unsigned>(h_col.data(), h_col.size(), &du); if (rc) return rc; m.h_col = du;
+        rc = dev_upload<float>(hblk.data(), hblk.size(), &df); if (rc) return rc; m.hblk = df;
+        // GRU B input weights for the two relay waves, j-major with lane = row: [384][64]
+        std::vector<float> gbl((size_t)NA * 64, 0.f);
+        for (int j = 0; j < NA; ++j)
+            for (int row = 0; row < NB3; ++row) gbl[(size_t)j * 64 + row] = v.gru_b_w_in[(size_t)j * NB3 + row];
+        rc = dev_upload<float>(gbl.data(), gbl.size(), &df); if (rc) return rc; m.gb_w_lane = df;
+    }
     // ---- derived tables (host libm, exactly as xiph builds them at run time) ---------------------------
     {
         float tansig[201], logit[256], u2l[256], dct[18 * 18], costab[320], ia[160], ib[160];
@@ -451,7 +523,7 @@ extern "C" int dss_lpcnet_batch_enable_trace(dss_lpcnet_batch *b, int on)
         rc |= dev_alloc<float>(n, &b->d.trace_pcm);
         if (rc) return DSS_ENOMEM;
     }
-    b->trace = on ? 1 : 0;
+    b->trace = on;      // 1 = excitation/pcm trace, 2 = diagnostic phase stamps (development only)
     return DSS_OK;
 }
 

@@ -20,6 +20,11 @@
 #define DSS_FC_OUT 256
 #define DSS_COND_STRIDE (3 * DSS_GRU_A + 3 * DSS_GRU_B + DSS_LPC_ORDER)   // 1216 floats per frame
 #define DSS_FEATURES_DELAY 2
+// Capacities of the CU-resident sample-rate kernel (lpcnet_sample.hip).  A model that exceeds any of them
+// (or whose h-gate block image does not fit DSS_HBLK_BYTES of LDS) runs on the generic kernel instead.
+#define DSS_ZRC 12            // register slots per lane for the z-gate and for the r-gate 8x4 blocks
+#define DSS_HC 28             // max h-gate blocks per row group (LDS resident; column ids in 7 VGPRs)
+#define DSS_HBLK_BYTES (132 * 1024)
 
 void dss_set_error(const char *fmt, ...);
 
@@ -61,6 +66,18 @@ struct DssModelDev {
     const float *interp_a, *interp_b;   // [160] (1-frac), frac of interp_band_gain
     const int *interp_band;       // [160] band index i of each bin
     const double *lag_window;     // [17] 1 - 6e-5*i*i
+    // register-resident layout of the sample-rate kernel (lpcnet_sample.hip)
+    int fast_ok;                  // 1 when the model fits the capacities above
+    int nzr_max;                  // max(z blocks, r blocks) over all row groups, rounded up to even
+    int hblk_floats;              // size of hblk
+    const int *unit_of;           // [384] lane of waves 0..5 -> GRU A unit (row groups sorted by h block count)
+    const int *wave_nh;           // [8]   per wave: h-gate slots (even), [6],[7] unused
+    const int *wave_hoff;         // [8]   per wave: float offset of its block records inside hblk
+    const float *zr_w;            // [2*DSS_ZRC][4][384] z then r block weights per lane slot, zero padded
+    const unsigned *zr_col;       // [2*DSS_ZRC/4][384]  four 8-bit block column ids (pos/4) per word
+    const unsigned *h_col;        // [DSS_HC/4][384]     same for the h-gate slots of the lane's row group
+    const float *hblk;            // LDS image: per wave, per group slot q (8), per block s: [8 rows][4]
+    const float *gb_w_lane;       // [384][64] GRU B input weights, input-major, lane = row (rows 48..63 zero)
 };
 
 // ---- per-batch device state ---------------------------------------------------------------------------
@@ -95,6 +112,8 @@ int dss_launch_frame_network(const DssModelDev &m, DssBatchDev &b, const float *
                              int feat_stride, hipStream_t s);
 int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
                               int trace, hipStream_t s);
+int dss_launch_sample_network_generic(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
+                                      int trace, hipStream_t s);
 int dss_launch_lpcnet_reset(const DssModelDev &m, DssBatchDev &b, int utt, hipStream_t s);
 
 struct DssHgaDev {

@@ -1,227 +1,387 @@
 // csrc/lpcnet_sample.hip -- LPCNet sample-rate (16 kHz autoregressive) network, one persistent
-// workgroup per utterance (gfx950).
+// workgroup per utterance, all weights resident on the CU (gfx950).
 //
 // Restates xiph/LPCNet src/lpcnet.c lpcnet_synthesize_tail_impl() + run_sample_network() and
 // src/nnet.c compute_gru_a_input / compute_sparse_gru / compute_gruB / sample_mdense (generic float path
 // of src/vec.h), as reached through the reference's binding extensions/lpcnet/cLPCNet.pxd:13.
 //
-// Work split inside the 512-thread workgroup (8 waves, 2 per SIMD), per output sample:
-//   wave 7        : "scalar" recurrences -- order-16 LPC prediction, mu-law, de-emphasis, kiss99, tree walk
-//   waves 0..5    : GRU A, lane = unit i of 384; each lane runs the z, r and h rows of its unit as three
-//                   independent sequential chains over its 8x4 sparse blocks (same summation order as the C)
-//   wave 6        : GRU B, lane = output row (48 rows), 384-term sequential chain from LDS-resident weights
-//   waves 0..3    : dual-FC, lane = tree node n of 256: both channels' 16-term chains, weights in VGPRs;
-//                   all 255 node logits are evaluated, the 8-level walk is then pure scalar bit tests
-// Every floating-point expression keeps the C source's association and precision (-ffp-contract=off).
+// Where the ~300 KB of weights live for the whole launch (per sample only the three 1152-float embedding
+// rows come from L2):
+//   GRU A z- and r-gate 8x4 blocks (15k floats)  VGPRs of waves 0..5 (lane = unit, 2 x DSS_ZRC slots)
+//   GRU A h-gate 8x4 blocks (30k floats)          LDS, one 128-byte record per block, grouped per wave
+//   GRU B input weights (18k floats)              VGPRs of waves 6 and 7 (lane = row; 208 + 128 inputs), last 64 in LDS
+//   dual-FC (8k floats)                           VGPRs of waves 0..3 (lane = tree node)
+// Roles inside the 512-thread workgroup (8 waves, 2 per SIMD); every wave runs the same barrier sequence
+// A B C D per sample:
+//   waves 0..5  GRU A.  A..B: embedding rows, z and r chains, activations, new state.  B..C: the h-gate
+//               recurrent chain of the NEXT sample (needs only the new state) -- hidden under GRU B.
+//               C..D (waves 0..3): dual-FC logits of all 255 tree nodes -> decision bits.
+//   wave 6      GRU B, inputs 0..207: lane = output row, one sequential chain per row, then hands the partial
+//               sums to wave 7 through LDS (flag, no barrier).
+//   wave 7      GRU B inputs 208..383 + gates, and the scalar recurrences: order-16 LPC prediction, mu-law,
+//               de-emphasis, kiss99 thresholds, tree walk, PCM output.
+// Summation order inside every row is exactly the C source's (one product at a time, ascending input),
+// and the library is built with -ffp-contract=off, so results are bit-identical to the scalar C path.
 #include "dss_common.h"
 #include "lpcnet_device.h"
 
 #define NA DSS_GRU_A
 #define NB DSS_GRU_B
 #define NB3 (3 * DSS_GRU_B)
+#define ZRC DSS_ZRC
+#define HC DSS_HC
+#define GBH6 208                          // GRU B inputs whose weights sit in wave 6's VGPRs (0..207)
+#define GBH7 112                          // ... in wave 7's VGPRs (208..319); wave 7 also carries the scalar state
+#define GBHL (NA - GBH6 - GBH7)           // ... and the last 64 inputs' weights in LDS, [row][GBL_STRIDE]
+#define GBL_STRIDE 68
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SampleLds {
-    float state_a[2][NA];        // double-buffered GRU A state
-    float gb_w[NA * NB3];        // GRU B input weights [384][48]
-    float gb_wrec[NB * NB3];     // GRU B recurrent weights [16][48]
+    float hblk[DSS_HBLK_BYTES / 4];       // h-gate block records
+    float state_a[2][NA];                 // double-buffered GRU A state
+    float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
+    float gb_wl[NB3 * GBL_STRIDE];        // GRU B input weights of the last GBHL inputs, row-major
     float tansig[208];
     float ulaw2lin[256];
     float logit_table[256];
+    float gb_acc[64];                     // GRU B partial sums handed from wave 6 to wave 7
     float state_b[NB];
     float thr[8];
-    unsigned bits[8];            // decision bit of every tree node (256 bits)
-    int idx[4];                  // last_sig_ulaw, pred_ulaw, last_exc
+    unsigned bits[8];                     // decision bit of every tree node (256 bits)
+    int idx[4];                           // last_sig_ulaw, pred_ulaw, last_exc
+    int gb_flag;                          // sequence number of the sample whose gb_acc is valid
+    int pad[3];
     short pcm[DSS_FRAME_SIZE];
 };
 
-template <bool TRACE>
+// one 8x4 block applied to one row: four products accumulated one at a time (sparse_sgemv_accum8x4 order)
+#define DSS_MAC4_REG(ACC, S)                                                                     \
+    {                                                                                            \
+        const unsigned col = (PZ[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu;                          \
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xbase + col * 16);                     \
+        ACC += W[S][0] * xv.x;                                                                   \
+        ACC += W[S][1] * xv.y;                                                                   \
+        ACC += W[S][2] * xv.z;                                                                   \
+        ACC += W[S][3] * xv.w;                                                                   \
+    }
+#define DSS_MAC4_LDS(ACC, S)                                                                     \
+    {                                                                                            \
+        const unsigned col = (PH[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu;                          \
+        const f32x4 wv = *reinterpret_cast<const f32x4 *>(hw + (S) * 128);                       \
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xbase + col * 16);                     \
+        ACC += wv.x * xv.x;                                                                      \
+        ACC += wv.y * xv.y;                                                                      \
+        ACC += wv.z * xv.z;                                                                      \
+        ACC += wv.w * xv.w;                                                                      \
+    }
+// h-gate chain of one lane: rbh + dgh*st, then its row group's blocks in idx order (end tested every 2 slots)
+#define DSS_H_CHAIN(XBUF)                                                                        \
+    {                                                                                            \
+        const char *xbase = reinterpret_cast<const char *>(XBUF);                                \
+        ah = rbh + dgh * st;                                                                     \
+        _Pragma("unroll") for (int s = 0; s < HC; s += 2) {                                      \
+            if (s >= nh) break;                                                                  \
+            DSS_MAC4_LDS(ah, s)                                                                  \
+            DSS_MAC4_LDS(ah, s + 1)                                                              \
+        }                                                                                        \
+    }
+// N inputs (multiple of 16) of the GRU B chain of one row.  Weights come from this lane's registers, the new
+// GRU A state from LDS (same address in every lane -> broadcast), fetched one group of 16 inputs ahead so the
+// LDS latency hides behind the previous group's arithmetic.  Products two at a time on aligned register
+// pairs (v_pk_mul_f32), sums strictly one at a time in input order.
+#define DSS_GB_GROUP(AV, G)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+        const f32x2 p0 = WB[2 * (4 * (G) + u)] * (AV)[u].lo;                                     \
+        const f32x2 p1 = WB[2 * (4 * (G) + u) + 1] * (AV)[u].hi;                                 \
+        acc += p0.x;                                                                             \
+        acc += p0.y;                                                                             \
+        acc += p1.x;                                                                             \
+        acc += p1.y;                                                                             \
+    }
+#define DSS_GB_LOAD(AV, AN, G)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
+        (AV)[u] = *reinterpret_cast<const f32x4 *>((AN) + 16 * (G) + 4 * u);
+#define DSS_GB_CHAIN(AN, N)                                                                      \
+    {                                                                                            \
+        f32x4 avA[4], avB[4];                                                                    \
+        DSS_GB_LOAD(avA, AN, 0)                                                                  \
+        _Pragma("unroll") for (int g = 0; g < (N) / 16; g += 2) {                                \
+            if (g + 1 < (N) / 16) DSS_GB_LOAD(avB, AN, g + 1)                                    \
+            __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch ahead of the arithmetic */ \
+            DSS_GB_GROUP(avA, g)                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 2 < (N) / 16) DSS_GB_LOAD(avA, AN, g + 2)                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 1 < (N) / 16) DSS_GB_GROUP(avB, g + 1)                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+
+template <bool TRACE, bool STAMP>
 __global__ void __launch_bounds__(512)
 lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restrict__ pcm_out)
 {
     __shared__ __attribute__((aligned(16))) SampleLds L;
     const int utt = blockIdx.x;
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
 
-    // ---------------- one-time staging ---------------------------------------------------------------
-    for (int k = tid; k < NA * NB3; k += 512) L.gb_w[k] = m.gru_b_w_in[k];
+    // ---------------- one-time staging into LDS -------------------------------------------------------
+    for (int k = tid * 4; k < m.hblk_floats; k += 512 * 4)
+        *reinterpret_cast<f32x4 *>(&L.hblk[k]) = *reinterpret_cast<const f32x4 *>(&m.hblk[k]);
     for (int k = tid; k < NB * NB3; k += 512) L.gb_wrec[k] = m.gru_b_w_rec[k];
+    for (int k = tid; k < NB3 * GBHL; k += 512) {
+        const int row = k / GBHL, j = k - row * GBHL;
+        L.gb_wl[row * GBL_STRIDE + j] = m.gb_w_lane[(size_t)(GBH6 + GBH7 + j) * 64 + row];
+    }
     if (tid < 201) L.tansig[tid] = m.tansig[tid];
     if (tid < 256) { L.ulaw2lin[tid] = m.ulaw2lin[tid]; L.logit_table[tid] = m.logit_table[tid]; }
     if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)utt * NA + tid];
     if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)utt * NB + tid];
-
-    // GRU A per-unit constants (waves 0..5)
-    float rbz = 0, rbr = 0, rbh = 0, dgz = 0, dgr = 0, dgh = 0;
-    if (tid < NA) {
-        rbz = m.gru_a_rbias[tid]; rbr = m.gru_a_rbias[NA + tid]; rbh = m.gru_a_rbias[2 * NA + tid];
-        dgz = m.gru_a_diag[tid];  dgr = m.gru_a_diag[NA + tid];  dgh = m.gru_a_diag[2 * NA + tid];
-    }
-    // dual-FC per-node constants (waves 0..3): node n = tid
-    float fw0[NB], fw1[NB], fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
-    if (tid < DSS_FC_OUT) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            fw0[j] = m.fc_w[(size_t)tid * 2 * NB + j];
-            fw1[j] = m.fc_w[(size_t)tid * 2 * NB + NB + j];
-        }
-        fb0 = m.fc_bias[tid]; fb1 = m.fc_bias[DSS_FC_OUT + tid];
-        ff0 = m.fc_factor[tid]; ff1 = m.fc_factor[DSS_FC_OUT + tid];
-    } else {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { fw0[j] = 0; fw1[j] = 0; }
-    }
-    // GRU B per-row constants (wave 6)
-    float gbb0 = 0, gbb1 = 0;
-    if (wave == 6 && lane < NB3) { gbb0 = m.gru_b_bias[lane]; gbb1 = m.gru_b_bias[NB3 + lane]; }
-    // scalar state (wave 7, replicated in every lane)
-    float last_sig[DSS_LPC_ORDER], lpc[DSS_LPC_ORDER];
-    float deemph = 0.f;
-    int last_exc = 0;
-    DssKiss99 rng = {0, 0, 0, 0};
-    if (wave == 7) {
-#pragma unroll
-        for (int j = 0; j < DSS_LPC_ORDER; ++j) last_sig[j] = b.last_sig[(size_t)utt * DSS_LPC_ORDER + j];
-        deemph = b.deemph[utt];
-        last_exc = b.last_exc[utt];
-        rng.z = b.rng[utt * 4 + 0]; rng.w = b.rng[utt * 4 + 1]; rng.jsr = b.rng[utt * 4 + 2]; rng.jcong = b.rng[utt * 4 + 3];
-    } else {
-#pragma unroll
-        for (int j = 0; j < DSS_LPC_ORDER; ++j) { last_sig[j] = 0; lpc[j] = 0; }
-    }
+    if (tid == 0) L.gb_flag = 0;
     const int fc0 = b.fc0[utt];
-    int cur = 0;
     __syncthreads();
 
-    for (int f = 0; f < n_frames; ++f) {
-        short *pcm_frame = pcm_out + ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE;
-        if (fc0 + f < DSS_FEATURES_DELAY) {                 // lpcnet.c: frame_count <= FEATURES_DELAY -> silence
-            if (tid < DSS_FRAME_SIZE / 2) reinterpret_cast<int *>(pcm_frame)[tid] = 0;
-            if (TRACE && tid < DSS_FRAME_SIZE) {
-                b.trace_exc[((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + tid] = -1.f;
-                b.trace_pcm[((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + tid] = 0.f;
+    if (wave < 6) {
+        // =====================================================================================================
+        // role A: GRU A (+ dual-FC on waves 0..3)
+        // =====================================================================================================
+        const int unit = m.unit_of[tid];
+        const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
+        const int nzr = m.nzr_max;
+        const char *hw = reinterpret_cast<const char *>(L.hblk + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
+                         ((lane >> 3) * nh * 128 + (lane & 7) * 16);
+        float W[2 * ZRC][4];
+        unsigned PZ[2 * ZRC / 4], PH[HC / 4];
+#pragma unroll
+        for (int s = 0; s < 2 * ZRC; ++s)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) W[s][k] = m.zr_w[((size_t)s * 4 + k) * NA + tid];
+#pragma unroll
+        for (int s = 0; s < 2 * ZRC / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
+#pragma unroll
+        for (int s = 0; s < HC / 4; ++s) PH[s] = m.h_col[(size_t)s * NA + tid];
+        const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + unit];
+        const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + unit];
+        // dual-FC constants of tree node `tid` (waves 0..3)
+        float fw0[NB], fw1[NB], fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
+        {
+            const int node = tid < DSS_FC_OUT ? tid : 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                fw0[j] = m.fc_w[(size_t)node * 2 * NB + j];
+                fw1[j] = m.fc_w[(size_t)node * 2 * NB + NB + j];
             }
-            continue;
+            fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
+            ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
         }
-        const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;
-        float cz = 0, cr = 0, ch = 0, gbc = 0;
-        if (tid < NA) { cz = fo[tid]; cr = fo[NA + tid]; ch = fo[2 * NA + tid]; }
-        if (wave == 6 && lane < NB3) gbc = fo[3 * NA + lane];
-        if (wave == 7) {
+        const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
+        int cur = 0;
+        float st = L.state_a[0][unit];
+        float ah;
+        DSS_H_CHAIN(L.state_a[0])                                    // first sample of this call
+
+        for (int f = 0; f < n_frames; ++f) {
+            if (fc0 + f < DSS_FEATURES_DELAY) continue;              // silent frame: decoder state untouched
+            const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;
+            const float cz = fo[unit], cr = fo[NA + unit], ch = fo[2 * NA + unit];
+            for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+                float az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
+                float ar = rbr + dgr * st;
+                __syncthreads();                                                        // barrier A
+                {
+                    const int si = L.idx[0], pi = L.idx[1], ei = L.idx[2];
+                    const float *es = m.embed_sig + (size_t)si * 3 * NA + unit;
+                    const float *ep = m.embed_pred + (size_t)pi * 3 * NA + unit;
+                    const float *ee = m.embed_exc + (size_t)ei * 3 * NA + unit;
+                    const float gz = ((cz + es[0]) + ep[0]) + ee[0];                    // compute_gru_a_input
+                    const float gr = ((cr + es[NA]) + ep[NA]) + ee[NA];
+                    const float gh = ((ch + es[2 * NA]) + ep[2 * NA]) + ee[2 * NA];
+                    az = az + gz;
+                    ar = ar + gr;
+                    const char *xbase = reinterpret_cast<const char *>(L.state_a[cur]);
+                    // z and r chains interleaved: two independent dependency chains per lane
+#pragma unroll
+                    for (int s = 0; s < ZRC; s += 2) {
+                        if (s >= nzr) break;
+                        DSS_MAC4_REG(az, s)
+                        DSS_MAC4_REG(ar, ZRC + s)
+                        DSS_MAC4_REG(az, s + 1)
+                        DSS_MAC4_REG(ar, ZRC + s + 1)
+                    }
+                    const float z = dss_sigmoid_approx(L.tansig, az);
+                    const float r = dss_sigmoid_approx(L.tansig, ar);
+                    float h = ah * r + gh;
+                    h = dss_tanh_approx(L.tansig, h);
+                    st = z * st + (1 - z) * h;
+                    L.state_a[cur ^ 1][unit] = st;
+                }
+                __syncthreads();                                                        // barrier B
+                DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
+                __syncthreads();                                                        // barrier C
+                if (tid < DSS_FC_OUT) {                                                 // sample_mdense, all nodes
+                    float s1 = fb0, s2 = fb1;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const float bj = L.state_b[j];
+                        s1 += fw0[j] * bj;
+                        s2 += fw1[j] * bj;
+                    }
+                    s1 = ff0 * dss_tanh_approx(L.tansig, s1);
+                    s2 = ff1 * dss_tanh_approx(L.tansig, s2);
+                    s1 += s2;
+                    const bool bit = L.thr[level] < s1;
+                    const unsigned long long mask = __ballot(bit);
+                    if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
+                }
+                __syncthreads();                                                        // barrier D
+                cur ^= 1;
+            }
+        }
+        __syncthreads();                                                                // final barrier
+        b.gru_a_state[(size_t)utt * NA + unit] = st;
+    } else if (wave == 6) {
+        // =====================================================================================================
+        // role B1: GRU B over inputs 0..207, lane = row (0..15 z, 16..31 r, 32..47 h)
+        // =====================================================================================================
+        f32x2 WB[GBH6 / 2];
+#pragma unroll
+        for (int j = 0; j < GBH6 / 2; ++j) {
+            WB[j].x = m.gb_w_lane[(size_t)(2 * j) * 64 + lane];
+            WB[j].y = m.gb_w_lane[(size_t)(2 * j + 1) * 64 + lane];
+        }
+        const int row = lane < NB3 ? lane : 0;
+        const float gbb0 = m.gru_b_bias[row];
+        int cur = 0, seq = 0;
+        for (int f = 0; f < n_frames; ++f) {
+            if (fc0 + f < DSS_FEATURES_DELAY) continue;
+            const float gbc = b.frame_out[((size_t)utt * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row];
+            for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+                float acc = gbb0 + gbc;                                                 // compute_gruB
+                ++seq;
+                __syncthreads();                                                        // barrier A
+                __syncthreads();                                                        // barrier B
+                const float *an = L.state_a[cur ^ 1];
+                DSS_GB_CHAIN(an, GBH6)
+                L.gb_acc[lane] = acc;
+                __hip_atomic_store(&L.gb_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __syncthreads();                                                        // barrier C
+                __syncthreads();                                                        // barrier D
+                cur ^= 1;
+            }
+        }
+        __syncthreads();                                                                // final barrier
+    } else {
+        // =====================================================================================================
+        // role B2 + S (wave 7): GRU B inputs 208..383 and gates; scalar recurrences replicated across lanes
+        // =====================================================================================================
+        f32x2 WB[GBH7 / 2];
+#pragma unroll
+        for (int j = 0; j < GBH7 / 2; ++j) {
+            WB[j].x = m.gb_w_lane[(size_t)(GBH6 + 2 * j) * 64 + lane];
+            WB[j].y = m.gb_w_lane[(size_t)(GBH6 + 2 * j + 1) * 64 + lane];
+        }
+        const int row = lane < NB3 ? lane : 0;
+        const float gbb1 = m.gru_b_bias[NB3 + row];
+        float last_sig[DSS_LPC_ORDER], lpc[DSS_LPC_ORDER];
+#pragma unroll
+        for (int j = 0; j < DSS_LPC_ORDER; ++j) { last_sig[j] = b.last_sig[(size_t)utt * DSS_LPC_ORDER + j]; lpc[j] = 0.f; }
+        float deemph = b.deemph[utt];
+        int last_exc = b.last_exc[utt];
+        DssKiss99 rng = {b.rng[utt * 4 + 0], b.rng[utt * 4 + 1], b.rng[utt * 4 + 2], b.rng[utt * 4 + 3]};
+        unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long t_prev = 0;
+        int cur = 0, seq = 0;
+        for (int f = 0; f < n_frames; ++f) {
+            short *pcm_frame = pcm_out + ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE;
+            if (fc0 + f < DSS_FEATURES_DELAY) {             // lpcnet.c: frame_count <= FEATURES_DELAY -> silence
+                for (int k = lane; k < DSS_FRAME_SIZE / 2; k += 64) reinterpret_cast<int *>(pcm_frame)[k] = 0;
+                if (TRACE)
+                    for (int k = lane; k < DSS_FRAME_SIZE; k += 64) {
+                        b.trace_exc[((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + k] = -1.f;
+                        b.trace_pcm[((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + k] = 0.f;
+                    }
+                continue;
+            }
+            const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;
 #pragma unroll
             for (int j = 0; j < DSS_LPC_ORDER; ++j) lpc[j] = fo[3 * NA + NB3 + j];
-        }
-
-        for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
-            // ---- P1 (wave 7): prediction, mu-law indices, sampling thresholds ------------------------
-            float pred = 0;
-            if (wave == 7) {
+            for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+                if (STAMP) t_prev = __builtin_readcyclecounter();
+                float pred = 0;
 #pragma unroll
                 for (int j = 0; j < DSS_LPC_ORDER; ++j) pred -= last_sig[j] * lpc[j];
                 const int su = dss_lin2ulaw(last_sig[0]);
                 const int pu = dss_lin2ulaw(pred);
-                const uint32_t r0 = dss_kiss99_rand(rng);
-                const uint32_t r1 = dss_kiss99_rand(rng);
                 if (lane == 0) { L.idx[0] = su; L.idx[1] = pu; L.idx[2] = last_exc; }
-                if (lane < 8) {
-                    const uint32_t r = lane < 4 ? r0 : r1;
-                    L.thr[lane] = L.logit_table[(r >> (8 * (lane & 3))) & 0xFF];
-                }
-            }
-            __syncthreads();                                                        // barrier A
-
-            // ---- P2 (waves 0..5): GRU A ----------------------------------------------------------------
-            if (tid < NA) {
-                const int si = L.idx[0], pi = L.idx[1], ei = L.idx[2];
-                const float *es = m.embed_sig + (size_t)si * 3 * NA + tid;
-                const float *ep = m.embed_pred + (size_t)pi * 3 * NA + tid;
-                const float *ee = m.embed_exc + (size_t)ei * 3 * NA + tid;
-                const float gz = ((cz + es[0]) + ep[0]) + ee[0];                    // compute_gru_a_input
-                const float gr = ((cr + es[NA]) + ep[NA]) + ee[NA];
-                const float gh = ((ch + es[2 * NA]) + ep[2 * NA]) + ee[2 * NA];
-                const float st = L.state_a[cur][tid];
-                float az = (rbz + dgz * st) + gz;                                   // compute_sparse_gru
-                float ar = (rbr + dgr * st) + gr;
-                float ah = rbh + dgh * st;
-                const char *xbase = reinterpret_cast<const char *>(L.state_a[cur]);
-#define DSS_GATE(G, ACC)                                                                         \
-                for (int sl = 0; sl < m.gate[G].slots; ++sl) {                                   \
-                    const int p4 = m.gate[G].pos4[sl * NA + tid];                                \
-                    const float *wp = m.gate[G].w + (size_t)sl * 4 * NA + tid;                   \
-                    const float4 xv = *reinterpret_cast<const float4 *>(xbase + p4);             \
-                    ACC += wp[0] * xv.x;                                                         \
-                    ACC += wp[NA] * xv.y;                                                        \
-                    ACC += wp[2 * NA] * xv.z;                                                    \
-                    ACC += wp[3 * NA] * xv.w;                                                    \
-                }
-                DSS_GATE(0, az)
-                DSS_GATE(1, ar)
-                DSS_GATE(2, ah)
-#undef DSS_GATE
-                const float z = dss_sigmoid_approx(L.tansig, az);
-                const float r = dss_sigmoid_approx(L.tansig, ar);
-                float h = ah * r + gh;
-                h = dss_tanh_approx(L.tansig, h);
-                L.state_a[cur ^ 1][tid] = z * st + (1 - z) * h;
-            }
-            __syncthreads();                                                        // barrier B
-
-            // ---- P3 (wave 6): GRU B ----------------------------------------------------------------------
-            if (wave == 6) {
-                const int row = lane < NB3 ? lane : 0;
-                const float *an = L.state_a[cur ^ 1];
-                float acc = gbb0 + gbc;                                            // compute_gruB
-                for (int j = 0; j < NA; j += 4) {
-                    const float4 av = *reinterpret_cast<const float4 *>(an + j);
-                    acc += L.gb_w[(j + 0) * NB3 + row] * av.x;
-                    acc += L.gb_w[(j + 1) * NB3 + row] * av.y;
-                    acc += L.gb_w[(j + 2) * NB3 + row] * av.z;
-                    acc += L.gb_w[(j + 3) * NB3 + row] * av.w;
+                ++seq;
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[0] += t - t_prev; t_prev = t; }
+                __syncthreads();                                                        // barrier A
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[1] += t - t_prev; t_prev = t; }
+                {   // off the critical path: this sample's 8 thresholds and GRU B's recurrent half
+                    const uint32_t r0 = dss_kiss99_rand(rng);
+                    const uint32_t r1 = dss_kiss99_rand(rng);
+                    if (lane < 8) {
+                        const uint32_t r = lane < 4 ? r0 : r1;
+                        L.thr[lane] = L.logit_table[(r >> (8 * (lane & 3))) & 0xFF];
+                    }
                 }
                 float rec = gbb1;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) rec += L.gb_wrec[j * NB3 + row] * L.state_b[j];
-                // lanes 0..15: z, 16..31: r, 32..47: h
-                const float zr = dss_sigmoid_approx(L.tansig, acc + rec);
-                const float r_for_h = __shfl(zr, lane - NB);                      // r_i for lane 32+i
-                float hh = acc + rec * r_for_h;
-                hh = dss_tanh_approx(L.tansig, hh);
-                const float h_for_z = __shfl(hh, lane + 2 * NB);                  // h_i for lane i
-                if (lane < NB) {
-                    const float sb = L.state_b[lane];
-                    L.state_b[lane] = zr * sb + (1 - zr) * h_for_z;
-                }
-            }
-            __syncthreads();                                                        // barrier C
-
-            // ---- P4 (waves 0..3): dual-FC logits of all tree nodes, decision bits ------------------------
-            if (tid < DSS_FC_OUT) {
-                float s1 = fb0, s2 = fb1;
+                __syncthreads();                                                        // barrier B
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[2] += t - t_prev; t_prev = t; }
+                while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
+                    __builtin_amdgcn_s_sleep(1);
+                float acc = L.gb_acc[lane];
+                {
+                    const float *an = L.state_a[cur ^ 1] + GBH6;
+                    DSS_GB_CHAIN(an, GBH7)
+                    const float *al = an + GBH7, *wl = L.gb_wl + row * GBL_STRIDE;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const float bj = L.state_b[j];
-                    s1 += fw0[j] * bj;
-                    s2 += fw1[j] * bj;
+                    for (int j4 = 0; j4 < GBHL / 4; ++j4) {
+                        const f32x4 av = *reinterpret_cast<const f32x4 *>(al + 4 * j4);
+                        const f32x4 wv = *reinterpret_cast<const f32x4 *>(wl + 4 * j4);
+                        const f32x2 p0 = wv.lo * av.lo, p1 = wv.hi * av.hi;
+                        acc += p0.x;
+                        acc += p0.y;
+                        acc += p1.x;
+                        acc += p1.y;
+                    }
                 }
-                s1 = ff0 * dss_tanh_approx(L.tansig, s1);
-                s2 = ff1 * dss_tanh_approx(L.tansig, s2);
-                s1 += s2;
-                const int level = 31 - __clz(tid | 1);                               // node = (1 << level) | prefix
-                const bool bit = L.thr[level] < s1;
-                const unsigned long long mask = __ballot(bit);
-                if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
-            }
-            __syncthreads();                                                        // barrier D
-
-            // ---- P6 (wave 7): walk the tree, finish the sample ----------------------------------------------
-            if (wave == 7) {
+                {   // gates: lanes 0..15 z, 16..31 r, 32..47 h
+                    const float zr = dss_sigmoid_approx(L.tansig, acc + rec);
+                    const float r_for_h = __shfl(zr, lane - NB);                      // r_i for lane 32+i
+                    float hh = acc + rec * r_for_h;
+                    hh = dss_tanh_approx(L.tansig, hh);
+                    const float h_for_z = __shfl(hh, lane + 2 * NB);                  // h_i for lane i
+                    if (lane < NB) {
+                        const float sb = L.state_b[lane];
+                        L.state_b[lane] = zr * sb + (1 - zr) * h_for_z;
+                    }
+                }
+                __syncthreads();                                                        // barrier C
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
+                __syncthreads();                                                        // barrier D
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[4] += t - t_prev; t_prev = t; }
+                cur ^= 1;
+                // walk the tree: every operand is wave-uniform, so this is scalar bit arithmetic
+                const uint4 b0 = *reinterpret_cast<const uint4 *>(&L.bits[0]);
+                const uint4 b1 = *reinterpret_cast<const uint4 *>(&L.bits[4]);
+                const unsigned long long m0 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.x);
+                const unsigned long long m1 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.z);
+                const unsigned long long m2 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.x);
+                const unsigned long long m3 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.z);
                 int val = 0;
 #pragma unroll
-                for (int lv = 0; lv < 8; ++lv) {
+                for (int lv = 0; lv < 6; ++lv) {                                        // nodes 1..63 live in m0
                     const int node = (1 << lv) | val;
-                    const unsigned wbits = L.bits[node >> 5];
-                    val = (val << 1) | ((wbits >> (node & 31)) & 1);
+                    val = (val << 1) | (int)((m0 >> node) & 1);
                 }
+                { const int node = 64 | val; val = (val << 1) | (int)((m1 >> (node - 64)) & 1); }
+                { const int node = 128 | val; const unsigned long long mm = node < 192 ? m2 : m3; val = (val << 1) | (int)((mm >> (node & 63)) & 1); }
                 const int exc = val;
                 float pcm = pred + L.ulaw2lin[exc];
                 if (TRACE && lane == 0) {
@@ -238,85 +398,36 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 if (pcm < -32767) pcm = -32767;
                 if (pcm > 32767) pcm = 32767;
                 if (lane == 0) L.pcm[i] = (short)(int)floor(.5 + (double)pcm);
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[5] += t - t_prev; t_prev = t; }
             }
-            cur ^= 1;
-            // no barrier needed here: wave 7 alone touches idx/thr/pcm before barrier A of the next sample,
-            // and bits[] is rewritten only after barriers A..C.
+            // wave 7 owns L.pcm: LDS operations of one wave are ordered, no barrier needed
+            for (int k = lane; k < DSS_FRAME_SIZE / 2; k += 64)
+                reinterpret_cast<int *>(pcm_frame)[k] = reinterpret_cast<const int *>(L.pcm)[k];
         }
-        __syncthreads();
-        if (tid < DSS_FRAME_SIZE / 2) reinterpret_cast<int *>(pcm_frame)[tid] = reinterpret_cast<const int *>(L.pcm)[tid];
-    }
-
-    // ---------------- write the persistent state back ------------------------------------------------------
-    __syncthreads();
-    if (tid < NA) b.gru_a_state[(size_t)utt * NA + tid] = L.state_a[cur][tid];
-    if (tid < NB) b.gru_b_state[(size_t)utt * NB + tid] = L.state_b[tid];
-    if (wave == 7 && lane == 0) {
+        __syncthreads();                                                                // final barrier
+        if (STAMP && lane == 0 && b.trace_pcm)          // diagnostic build only
+            for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)utt * 6 + k] = (float)stamp_acc[k];
+        if (lane < NB) b.gru_b_state[(size_t)utt * NB + lane] = L.state_b[lane];
+        if (lane == 0) {
 #pragma unroll
-        for (int j = 0; j < DSS_LPC_ORDER; ++j) b.last_sig[(size_t)utt * DSS_LPC_ORDER + j] = last_sig[j];
-        b.deemph[utt] = deemph;
-        b.last_exc[utt] = last_exc;
-        b.rng[utt * 4 + 0] = rng.z; b.rng[utt * 4 + 1] = rng.w; b.rng[utt * 4 + 2] = rng.jsr; b.rng[utt * 4 + 3] = rng.jcong;
+            for (int j = 0; j < DSS_LPC_ORDER; ++j) b.last_sig[(size_t)utt * DSS_LPC_ORDER + j] = last_sig[j];
+            b.deemph[utt] = deemph;
+            b.last_exc[utt] = last_exc;
+            b.rng[utt * 4 + 0] = rng.z; b.rng[utt * 4 + 1] = rng.w; b.rng[utt * 4 + 2] = rng.jsr; b.rng[utt * 4 + 3] = rng.jcong;
+        }
     }
 }
 
 int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm, int trace,
                               hipStream_t s)
 {
-    if (trace)
-        hipLaunchKernelGGL(lpcnet_sample_kernel<true>, dim3(n_utts), dim3(512), 0, s, m, b, n_frames, d_pcm);
+    if (!m.fast_ok || trace >= 16) return dss_launch_sample_network_generic(m, b, n_utts, n_frames, d_pcm, trace & 15, s);
+    if (trace == 2)        // diagnostic: phase stamps written into trace_pcm (never used for timing claims)
+        hipLaunchKernelGGL((lpcnet_sample_kernel<false, true>), dim3(n_utts), dim3(512), 0, s, m, b, n_frames, d_pcm);
+    else if (trace)
+        hipLaunchKernelGGL((lpcnet_sample_kernel<true, false>), dim3(n_utts), dim3(512), 0, s, m, b, n_frames, d_pcm);
     else
-        hipLaunchKernelGGL(lpcnet_sample_kernel<false>, dim3(n_utts), dim3(512), 0, s, m, b, n_frames, d_pcm);
-    DSS_HIP_CHECK(hipGetLastError());
-    return DSS_OK;
-}
-
-// lpcnet_init(): zero state, last_exc = lin2ulaw(0), kiss99_srand("LPCNet")
-__global__ void lpcnet_reset_kernel(DssBatchDev b, int utt_only, int n_utts, DssKiss99 seed, int exc0)
-{
-    const int utt = utt_only >= 0 ? utt_only : blockIdx.x;
-    if (utt >= n_utts) return;
-    const int tid = threadIdx.x;
-    for (int k = tid; k < NA; k += blockDim.x) b.gru_a_state[(size_t)utt * NA + k] = 0.f;
-    for (int k = tid; k < 2 * 128; k += blockDim.x) b.conv2_mem[(size_t)utt * 2 * 128 + k] = 0.f;
-    for (int k = tid; k < 2 * 84; k += blockDim.x) b.conv1_mem[(size_t)utt * 2 * 84 + k] = 0.f;
-    if (tid < NB) b.gru_b_state[(size_t)utt * NB + tid] = 0.f;
-    if (tid < DSS_LPC_ORDER) b.last_sig[(size_t)utt * DSS_LPC_ORDER + tid] = 0.f;
-    if (tid < 2 * DSS_LPC_ORDER) b.old_lpc[(size_t)utt * 2 * DSS_LPC_ORDER + tid] = 0.f;
-    if (tid == 0) {
-        b.last_exc[utt] = exc0;
-        b.deemph[utt] = 0.f;
-        b.frame_count[utt] = 0;
-        b.rng[utt * 4 + 0] = seed.z; b.rng[utt * 4 + 1] = seed.w; b.rng[utt * 4 + 2] = seed.jsr; b.rng[utt * 4 + 3] = seed.jcong;
-    }
-}
-
-int dss_launch_lpcnet_reset(const DssModelDev &m, DssBatchDev &b, int utt, hipStream_t s)
-{
-    // kiss99_srand(&rng, "LPCNet", 6) evaluated on the host (integer only)
-    DssKiss99 c = {362436069u, 521288629u, 123456789u, 380116160u};
-    const unsigned char data[6] = {'L', 'P', 'C', 'N', 'e', 't'};
-    const int n = 6;
-    int i;
-    for (i = 3; i < n; i += 4) {
-        c.z ^= data[i - 3]; c.w ^= data[i - 2]; c.jsr ^= data[i - 1]; c.jcong ^= data[i];
-        // one kiss99_rand step
-        const uint32_t znew = 36969u * (c.z & 0xFFFF) + (c.z >> 16);
-        const uint32_t wnew = 18000u * (c.w & 0xFFFF) + (c.w >> 16);
-        uint32_t shr3 = c.jsr ^ (c.jsr << 17);
-        shr3 ^= shr3 >> 13;
-        shr3 ^= shr3 << 5;
-        c.z = znew; c.w = wnew; c.jsr = shr3; c.jcong = 69069u * c.jcong + 1234567u;
-    }
-    if (i - 3 < n) c.z ^= data[i - 3];
-    if (i - 2 < n) c.w ^= data[i - 2];
-    if (i - 1 < n) c.jsr ^= data[i - 1];
-    if (c.z == 0 || c.z == 0x9068FFFF) c.z++;
-    if (c.w == 0 || c.w == 0x464FFFFF) c.w++;
-    if (c.jsr == 0) c.jsr++;
-    const int exc0 = 128;   // lin2ulaw(0.f): 128 + 128*log_approx(1)/LOG256 = 128.007 -> 128
-    const int grid = utt >= 0 ? 1 : b.max_utts;
-    hipLaunchKernelGGL(lpcnet_reset_kernel, dim3(grid), dim3(256), 0, s, b, utt, b.max_utts, c, exc0);
+        hipLaunchKernelGGL((lpcnet_sample_kernel<false, false>), dim3(n_utts), dim3(512), 0, s, m, b, n_frames, d_pcm);
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }

@@ -1,0 +1,22 @@
+"""Development aid: per-phase cycle shares of the sample kernel (diagnostic build with s_memtime stamps)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "delayed-speech-synthesis_amd"))
+import numpy as np, torch
+from dss_amd import _lib
+from dss_amd.lpcnet import LPCNetBatch
+from dss_amd.lpcnet_weights import synthetic_features
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+F = 20
+feats = np.stack([synthetic_features(b, F) for b in range(B)])
+gpu = LPCNetBatch(B, F)
+gpu.enable_trace(2)
+gpu.synthesize(feats)
+n = (F - 2) * 160
+raw = np.empty((F * 160,), np.float32)
+names = ["P1 work", "wait A", "A->B (GRU A)", "B->C (GRU B)", "C->D (FC)", "P6 / idle"]
+_lib.check(gpu._L.dss_lpcnet_batch_tap(gpu._h, 0, 4, raw.ctypes.data, raw.size))   # trace_pcm holds the stamps
+st = raw[: B * 6].reshape(B, 6) / n
+print("wave 7 (scalar role) view, cycles per sample, mean over utterances:")
+print("  " + "  ".join(f"{names[k]}={st[:, k].mean():8.1f}" for k in range(6)), " total", st.sum(axis=1).mean())
+print("  min/max total over utterances:", st.sum(axis=1).min(), st.sum(axis=1).max())
