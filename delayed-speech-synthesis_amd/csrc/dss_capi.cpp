@@ -308,21 +308,35 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         std::vector<int> order(G);
         for (int g = 0; g < G; ++g) order[g] = g;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return cnt[2 * G + a] > cnt[2 * G + b2]; });
-        std::vector<int> unit_of(NA, 0), wave_nh(8, 0), wave_hoff(8, 0);
+        // sorted rank -> wave: waves (0,4) and (1,5) share a SIMD, waves 2 and 3 share theirs with the GRU B
+        // relay waves, so pair the heaviest chunk with the lightest and give the middle ones to waves 2, 3
+        static const int rank_wave[6] = {0, 1, 2, 3, 5, 4};
+        std::vector<int> unit_of(NA, 0), wave_nh(8, 0), wave_hoff(8, 0), wave_nzr(8, 0), grp_of_slot(G, 0);
         int hfloats = 0;
+        for (int rk = 0; rk < 6 && fast_ok; ++rk) {
+            const int wv = rank_wave[rk];
+            int nh = 0, nzr = 0;
+            for (int q = 0; q < 8; ++q) {
+                const int grp = order[rk * 8 + q];
+                grp_of_slot[wv * 8 + q] = grp;
+                nh = std::max(nh, cnt[2 * G + grp]);
+                nzr = std::max(nzr, std::max(cnt[grp], cnt[G + grp]));
+            }
+            wave_nh[wv] = (nh + 1) & ~1;            // the kernel tests for the end of a list every 2 slots
+            wave_nzr[wv] = (nzr + 1) & ~1;
+        }
         for (int wv = 0; wv < 6 && fast_ok; ++wv) {
-            int nh = 0;
-            for (int q = 0; q < 8; ++q) nh = std::max(nh, cnt[2 * G + order[wv * 8 + q]]);
-            nh = (nh + 1) & ~1;                     // the kernel tests for the end of the list every 2 slots
-            wave_nh[wv] = nh; wave_hoff[wv] = hfloats;
-            hfloats += 8 * nh * 32;
+            wave_hoff[wv] = hfloats;
+            // one extra 128-byte record per group: consecutive groups then start 32 banks apart, which makes
+            // the 16-lane phases of a wave's ds_read_b128 of its block records conflict-free
+            hfloats += 8 * (wave_nh[wv] + 1) * 32;
         }
         if ((size_t)hfloats * sizeof(float) > DSS_HBLK_BYTES) fast_ok = 0;
         std::vector<float> zr_w((size_t)2 * DSS_ZRC * 4 * NA, 0.f), hblk((size_t)std::max(hfloats, 4), 0.f);
         std::vector<unsigned> zr_col((size_t)(2 * DSS_ZRC / 4) * NA, 0u), h_col((size_t)(DSS_HC / 4) * NA, 0u);
         if (fast_ok)
             for (int tid = 0; tid < NA; ++tid) {
-                const int wv = tid / 64, l = tid & 63, q = l / 8, r = l & 7, grp = order[wv * 8 + q];
+                const int wv = tid / 64, l = tid & 63, q = l / 8, r = l & 7, grp = grp_of_slot[wv * 8 + q];
                 unit_of[tid] = grp * 8 + r;
                 for (int gate = 0; gate < 2; ++gate) {
                     const int g = gate * G + grp;
@@ -336,7 +350,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
                 const int g = 2 * G + grp;
                 for (int sl = 0; sl < cnt[g]; ++sl) {
                     const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                    float *rec = hblk.data() + wave_hoff[wv] + ((size_t)q * wave_nh[wv] + sl) * 32 + r * 4;
+                    float *rec = hblk.data() + wave_hoff[wv] + ((size_t)q * (wave_nh[wv] + 1) + sl) * 32 + r * 4;
                     for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
                     h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
                 }
@@ -348,6 +362,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         rc = dev_upload<int>(unit_of.data(), unit_of.size(), &di); if (rc) return rc; m.unit_of = di;
         rc = dev_upload<int>(wave_nh.data(), wave_nh.size(), &di); if (rc) return rc; m.wave_nh = di;
         rc = dev_upload<int>(wave_hoff.data(), wave_hoff.size(), &di); if (rc) return rc; m.wave_hoff = di;
+        rc = dev_upload<int>(wave_nzr.data(), wave_nzr.size(), &di); if (rc) return rc; m.wave_nzr = di;
         rc = dev_upload<float>(zr_w.data(), zr_w.size(), &df); if (rc) return rc; m.zr_w = df;
         rc = dev_upload<unsigned>(zr_col.data(), zr_col.size(), &du); if (rc) return rc; m.zr_col = du;
         rc = dev_upload<unsigned>(h_col.data(), h_col.size(), &du); if (rc) return rc; m.h_col = du;

@@ -24,7 +24,7 @@
 // (or whose h-gate block image does not fit DSS_HBLK_BYTES of LDS) runs on the generic kernel instead.
 #define DSS_ZRC 12            // register slots per lane for the z-gate and for the r-gate 8x4 blocks
 #define DSS_HC 28             // max h-gate blocks per row group (LDS resident; column ids in 7 VGPRs)
-#define DSS_HBLK_BYTES (132 * 1024)
+#define DSS_HBLK_BYTES 140000  // dynamic LDS left after the kernel's static 22.3 KB (160 KB per CU)
 
 void dss_set_error(const char *fmt, ...);
 
@@ -73,10 +73,11 @@ struct DssModelDev {
     const int *unit_of;           // [384] lane of waves 0..5 -> GRU A unit (row groups sorted by h block count)
     const int *wave_nh;           // [8]   per wave: h-gate slots (even), [6],[7] unused
     const int *wave_hoff;         // [8]   per wave: float offset of its block records inside hblk
+    const int *wave_nzr;          // [8]   per wave: z/r slots actually used (even)
     const float *zr_w;            // [2*DSS_ZRC][4][384] z then r block weights per lane slot, zero padded
     const unsigned *zr_col;       // [2*DSS_ZRC/4][384]  four 8-bit block column ids (pos/4) per word
     const unsigned *h_col;        // [DSS_HC/4][384]     same for the h-gate slots of the lane's row group
-    const float *hblk;            // LDS image: per wave, per group slot q (8), per block s: [8 rows][4]
+    const float *hblk;            // LDS image: per wave, per group slot q (8): nh+1 records of [8 rows][4]
     const float *gb_w_lane;       // [384][64] GRU B input weights, input-major, lane = row (rows 48..63 zero)
 };
 

@@ -38,7 +38,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SampleLds {
-    float hblk[DSS_HBLK_BYTES / 4];       // h-gate block records
     float state_a[2][NA];                 // double-buffered GRU A state
     float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
     float gb_wl[NB3 * GBL_STRIDE];        // GRU B input weights of the last GBHL inputs, row-major
@@ -56,34 +55,63 @@ struct SampleLds {
 };
 
 // one 8x4 block applied to one row: four products accumulated one at a time (sparse_sgemv_accum8x4 order)
-#define DSS_MAC4_REG(ACC, S)                                                                     \
+// z/r chunk C = slots 2C, 2C+1 of the z list and of the r list (Q[0..1] z, Q[2..3] r)
+#define DSS_ZR_COL(S) ((PZ[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu)
+#define DSS_ZR_LOADX(Q, C)                                                                       \
     {                                                                                            \
-        const unsigned col = (PZ[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu;                          \
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xbase + col * 16);                     \
-        ACC += W[S][0] * xv.x;                                                                   \
-        ACC += W[S][1] * xv.y;                                                                   \
-        ACC += W[S][2] * xv.z;                                                                   \
-        ACC += W[S][3] * xv.w;                                                                   \
+        Q[0] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(2 * (C)) * 16);               \
+        Q[1] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(2 * (C) + 1) * 16);           \
+        Q[2] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(ZRC + 2 * (C)) * 16);         \
+        Q[3] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(ZRC + 2 * (C) + 1) * 16);     \
     }
-#define DSS_MAC4_LDS(ACC, S)                                                                     \
+#define DSS_ZR_MUL(Q, C)                                                                         \
     {                                                                                            \
-        const unsigned col = (PH[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu;                          \
-        const f32x4 wv = *reinterpret_cast<const f32x4 *>(hw + (S) * 128);                       \
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xbase + col * 16);                     \
-        ACC += wv.x * xv.x;                                                                      \
-        ACC += wv.y * xv.y;                                                                      \
-        ACC += wv.z * xv.z;                                                                      \
-        ACC += wv.w * xv.w;                                                                      \
+        Q[0].lo = WZ[2 * (C)].lo * Q[0].lo;             Q[0].hi = WZ[2 * (C)].hi * Q[0].hi;             \
+        Q[1].lo = WZ[2 * (C) + 1].lo * Q[1].lo;         Q[1].hi = WZ[2 * (C) + 1].hi * Q[1].hi;         \
+        Q[2].lo = WZ[ZRC + 2 * (C)].lo * Q[2].lo;       Q[2].hi = WZ[ZRC + 2 * (C)].hi * Q[2].hi;       \
+        Q[3].lo = WZ[ZRC + 2 * (C) + 1].lo * Q[3].lo;   Q[3].hi = WZ[ZRC + 2 * (C) + 1].hi * Q[3].hi;   \
     }
-// h-gate chain of one lane: rbh + dgh*st, then its row group's blocks in idx order (end tested every 2 slots)
+#define DSS_ZR_ADD(Q)                                                                            \
+    {                                                                                            \
+        az += Q[0].x; ar += Q[2].x; az += Q[0].y; ar += Q[2].y;                                  \
+        az += Q[0].z; ar += Q[2].z; az += Q[0].w; ar += Q[2].w;                                  \
+        az += Q[1].x; ar += Q[3].x; az += Q[1].y; ar += Q[3].y;                                  \
+        az += Q[1].z; ar += Q[3].z; az += Q[1].w; ar += Q[3].w;                                  \
+    }
+// h-gate chain of one lane: rbh + dgh*st, then its row group's blocks in idx order.  Chunk C = slots 2C, 2C+1;
+// block records (LDS) and state vectors of the next chunk are fetched while the current chunk's sums run.
+#define DSS_H_COL(S) ((PH[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu)
+#define DSS_H_LOAD(Q, C)                                                                         \
+    {                                                                                            \
+        Q[0] = *reinterpret_cast<const f32x4 *>(hw + (2 * (C)) * 128);                           \
+        Q[1] = *reinterpret_cast<const f32x4 *>(hw + (2 * (C) + 1) * 128);                       \
+        Q[2] = *reinterpret_cast<const f32x4 *>(xbase + DSS_H_COL(2 * (C)) * 16);                \
+        Q[3] = *reinterpret_cast<const f32x4 *>(xbase + DSS_H_COL(2 * (C) + 1) * 16);            \
+    }
+#define DSS_H_MAC(Q)                                                                             \
+    {                                                                                            \
+        const f32x2 p0 = Q[0].lo * Q[2].lo, p1 = Q[0].hi * Q[2].hi;                              \
+        const f32x2 p2 = Q[1].lo * Q[3].lo, p3 = Q[1].hi * Q[3].hi;                              \
+        ah += p0.x; ah += p0.y; ah += p1.x; ah += p1.y;                                          \
+        ah += p2.x; ah += p2.y; ah += p3.x; ah += p3.y;                                          \
+    }
 #define DSS_H_CHAIN(XBUF)                                                                        \
     {                                                                                            \
         const char *xbase = reinterpret_cast<const char *>(XBUF);                                \
+        f32x4 HA[4], HB[4];                                                                      \
         ah = rbh + dgh * st;                                                                     \
-        _Pragma("unroll") for (int s = 0; s < HC; s += 2) {                                      \
-            if (s >= nh) break;                                                                  \
-            DSS_MAC4_LDS(ah, s)                                                                  \
-            DSS_MAC4_LDS(ah, s + 1)                                                              \
+        DSS_H_LOAD(HA, 0)                                                                        \
+        _Pragma("unroll") for (int c = 0; c < HC / 2; c += 2) {                                  \
+            if (2 * c >= nh) break;                                                              \
+            if (2 * (c + 1) < nh) DSS_H_LOAD(HB, c + 1)                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_H_MAC(HA)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (2 * (c + 1) >= nh) break;                                                        \
+            if (2 * (c + 2) < nh) DSS_H_LOAD(HA, c + 2)                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_H_MAC(HB)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
     }
 // N inputs (multiple of 16) of the GRU B chain of one row.  Weights come from this lane's registers, the new
@@ -118,11 +146,31 @@ struct SampleLds {
         }                                                                                        \
     }
 
+// the same chain over the inputs whose weights live in LDS (wave 7's tail): 8 inputs per group
+#define DSS_GBL_LOAD(T, G)                                                                       \
+    {                                                                                            \
+        T[0] = *reinterpret_cast<const f32x4 *>(al + 8 * (G));                                   \
+        T[1] = *reinterpret_cast<const f32x4 *>(al + 8 * (G) + 4);                               \
+        T[2] = *reinterpret_cast<const f32x4 *>(wl + 8 * (G));                                   \
+        T[3] = *reinterpret_cast<const f32x4 *>(wl + 8 * (G) + 4);                               \
+    }
+#define DSS_GBL_GROUP(T)                                                                         \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+        const f32x2 p0 = T[2 + u].lo * T[u].lo;                                                  \
+        const f32x2 p1 = T[2 + u].hi * T[u].hi;                                                  \
+        acc += p0.x;                                                                             \
+        acc += p0.y;                                                                             \
+        acc += p1.x;                                                                             \
+        acc += p1.y;                                                                             \
+    }
+
 template <bool TRACE, bool STAMP>
 __global__ void __launch_bounds__(512)
 lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restrict__ pcm_out)
 {
     __shared__ __attribute__((aligned(16))) SampleLds L;
+    extern __shared__ __attribute__((aligned(16))) float hblk_lds[];       // h-gate block records (size per model)
+    static_assert(sizeof(SampleLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
     const int utt = blockIdx.x;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -130,7 +178,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
 
     // ---------------- one-time staging into LDS -------------------------------------------------------
     for (int k = tid * 4; k < m.hblk_floats; k += 512 * 4)
-        *reinterpret_cast<f32x4 *>(&L.hblk[k]) = *reinterpret_cast<const f32x4 *>(&m.hblk[k]);
+        *reinterpret_cast<f32x4 *>(&hblk_lds[k]) = *reinterpret_cast<const f32x4 *>(&m.hblk[k]);
     for (int k = tid; k < NB * NB3; k += 512) L.gb_wrec[k] = m.gru_b_w_rec[k];
     for (int k = tid; k < NB3 * GBHL; k += 512) {
         const int row = k / GBHL, j = k - row * GBHL;
@@ -150,15 +198,18 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         // =====================================================================================================
         const int unit = m.unit_of[tid];
         const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
-        const int nzr = m.nzr_max;
-        const char *hw = reinterpret_cast<const char *>(L.hblk + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
-                         ((lane >> 3) * nh * 128 + (lane & 7) * 16);
-        float W[2 * ZRC][4];
+        const int nzr = __builtin_amdgcn_readfirstlane(m.wave_nzr[wave]);
+        const char *hw = reinterpret_cast<const char *>(hblk_lds + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
+                         ((lane >> 3) * (nh + 1) * 128 + (lane & 7) * 16);
+        f32x4 WZ[2 * ZRC];
         unsigned PZ[2 * ZRC / 4], PH[HC / 4];
 #pragma unroll
-        for (int s = 0; s < 2 * ZRC; ++s)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) W[s][k] = m.zr_w[((size_t)s * 4 + k) * NA + tid];
+        for (int s = 0; s < 2 * ZRC; ++s) {
+            WZ[s].x = m.zr_w[((size_t)s * 4 + 0) * NA + tid];
+            WZ[s].y = m.zr_w[((size_t)s * 4 + 1) * NA + tid];
+            WZ[s].z = m.zr_w[((size_t)s * 4 + 2) * NA + tid];
+            WZ[s].w = m.zr_w[((size_t)s * 4 + 3) * NA + tid];
+        }
 #pragma unroll
         for (int s = 0; s < 2 * ZRC / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
 #pragma unroll
@@ -181,6 +232,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         int cur = 0;
         float st = L.state_a[0][unit];
         float ah;
+        unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
         DSS_H_CHAIN(L.state_a[0])                                    // first sample of this call
 
         for (int f = 0; f < n_frames; ++f) {
@@ -188,39 +240,69 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;
             const float cz = fo[unit], cr = fo[NA + unit], ch = fo[2 * NA + unit];
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+                // keep the packed column ids opaque so the per-slot unpacking is not hoisted out of the sample
+                // loop into (spilled) registers
+#pragma unroll
+                for (int k = 0; k < 2 * ZRC / 4; ++k) asm volatile("" : "+v"(PZ[k]));
+#pragma unroll
+                for (int k = 0; k < HC / 4; ++k) asm volatile("" : "+v"(PH[k]));
                 float az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
                 float ar = rbr + dgr * st;
                 __syncthreads();                                                        // barrier A
+                if (STAMP) ta = __builtin_readcyclecounter();
                 {
                     const int si = L.idx[0], pi = L.idx[1], ei = L.idx[2];
                     const float *es = m.embed_sig + (size_t)si * 3 * NA + unit;
                     const float *ep = m.embed_pred + (size_t)pi * 3 * NA + unit;
                     const float *ee = m.embed_exc + (size_t)ei * 3 * NA + unit;
-                    const float gz = ((cz + es[0]) + ep[0]) + ee[0];                    // compute_gru_a_input
-                    const float gr = ((cr + es[NA]) + ep[NA]) + ee[NA];
-                    const float gh = ((ch + es[2 * NA]) + ep[2 * NA]) + ee[2 * NA];
-                    az = az + gz;
-                    ar = ar + gr;
+                    // the nine embedding values of this lane: loads issued here, consumed after the first products
+                    const float es0 = es[0], es1 = es[NA], es2 = es[2 * NA];
+                    const float ep0 = ep[0], ep1 = ep[NA], ep2 = ep[2 * NA];
+                    const float ee0 = ee[0], ee1 = ee[NA], ee2 = ee[2 * NA];
+                    // z and r chains, two slots of each per chunk, two in-place buffers: a chunk's state reads and
+                    // products (independent of the embedding rows) are issued while the other chunk's dependent
+                    // sums run, and the first two chunks' in the shadow of the embedding loads.
                     const char *xbase = reinterpret_cast<const char *>(L.state_a[cur]);
-                    // z and r chains interleaved: two independent dependency chains per lane
+                    f32x4 QA[4], QB[4];
+                    DSS_ZR_LOADX(QA, 0)
+                    if (2 < nzr) DSS_ZR_LOADX(QB, 1)
+                    DSS_ZR_MUL(QA, 0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[0] += t - ta; ta = t; }
+                    const float gz = ((cz + es0) + ep0) + ee0;                          // compute_gru_a_input
+                    const float gr = ((cr + es1) + ep1) + ee1;
+                    const float gh = ((ch + es2) + ep2) + ee2;
+                    az = az + gz;                       // (bias + diag*state) + input, then the blocks in idx order
+                    ar = ar + gr;
+                    if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[1] += t - ta; ta = t; }
 #pragma unroll
-                    for (int s = 0; s < ZRC; s += 2) {
-                        if (s >= nzr) break;
-                        DSS_MAC4_REG(az, s)
-                        DSS_MAC4_REG(ar, ZRC + s)
-                        DSS_MAC4_REG(az, s + 1)
-                        DSS_MAC4_REG(ar, ZRC + s + 1)
+                    for (int c = 0; c < ZRC / 2; c += 2) {
+                        if (2 * c >= nzr) break;
+                        if (2 * (c + 1) < nzr) DSS_ZR_MUL(QB, c + 1)
+                        DSS_ZR_ADD(QA)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (2 * (c + 2) < nzr) DSS_ZR_LOADX(QA, c + 2)
+                        if (2 * (c + 1) >= nzr) break;
+                        DSS_ZR_ADD(QB)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (2 * (c + 3) < nzr) DSS_ZR_LOADX(QB, c + 3)
+                        if (2 * (c + 2) < nzr) DSS_ZR_MUL(QA, c + 2)
                     }
+                    if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
                     const float z = dss_sigmoid_approx(L.tansig, az);
                     const float r = dss_sigmoid_approx(L.tansig, ar);
                     float h = ah * r + gh;
                     h = dss_tanh_approx(L.tansig, h);
                     st = z * st + (1 - z) * h;
                     L.state_a[cur ^ 1][unit] = st;
+                    if (STAMP) { asm volatile("" :: "v"(st)); unsigned long long t = __builtin_readcyclecounter(); sa[3] += t - ta; ta = t; }
                 }
                 __syncthreads();                                                        // barrier B
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
                 DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
+                if (STAMP) { asm volatile("" :: "v"(ah)); unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
                 __syncthreads();                                                        // barrier C
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
                 if (tid < DSS_FC_OUT) {                                                 // sample_mdense, all nodes
                     float s1 = fb0, s2 = fb1;
 #pragma unroll
@@ -237,10 +319,13 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
                 }
                 __syncthreads();                                                        // barrier D
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[7] += t - ta; ta = t; }
                 cur ^= 1;
             }
         }
         __syncthreads();                                                                // final barrier
+        if (STAMP && lane == 0 && b.trace_exc)
+            for (int k = 0; k < 8; ++k) b.trace_exc[((size_t)utt * 6 + wave) * 8 + k] = (float)sa[k];
         b.gru_a_state[(size_t)utt * NA + unit] = st;
     } else if (wave == 6) {
         // =====================================================================================================
@@ -264,7 +349,9 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 __syncthreads();                                                        // barrier A
                 __syncthreads();                                                        // barrier B
                 const float *an = L.state_a[cur ^ 1];
+                __builtin_amdgcn_s_setprio(3);            // the sample's critical chain: win VALU arbitration
                 DSS_GB_CHAIN(an, GBH6)
+                __builtin_amdgcn_s_setprio(0);
                 L.gb_acc[lane] = acc;
                 __hip_atomic_store(&L.gb_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __syncthreads();                                                        // barrier C
@@ -336,19 +423,23 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
                     __builtin_amdgcn_s_sleep(1);
                 float acc = L.gb_acc[lane];
+                __builtin_amdgcn_s_setprio(3);
                 {
                     const float *an = L.state_a[cur ^ 1] + GBH6;
                     DSS_GB_CHAIN(an, GBH7)
                     const float *al = an + GBH7, *wl = L.gb_wl + row * GBL_STRIDE;
+                    f32x4 tA[4], tB[4];                   // [0..1] state, [2..3] weights of two groups of 4 inputs
+                    DSS_GBL_LOAD(tA, 0)
 #pragma unroll
-                    for (int j4 = 0; j4 < GBHL / 4; ++j4) {
-                        const f32x4 av = *reinterpret_cast<const f32x4 *>(al + 4 * j4);
-                        const f32x4 wv = *reinterpret_cast<const f32x4 *>(wl + 4 * j4);
-                        const f32x2 p0 = wv.lo * av.lo, p1 = wv.hi * av.hi;
-                        acc += p0.x;
-                        acc += p0.y;
-                        acc += p1.x;
-                        acc += p1.y;
+                    for (int g = 0; g < GBHL / 8; g += 2) {
+                        if (g + 1 < GBHL / 8) DSS_GBL_LOAD(tB, g + 1)
+                        __builtin_amdgcn_sched_barrier(0);
+                        DSS_GBL_GROUP(tA)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g + 2 < GBHL / 8) DSS_GBL_LOAD(tA, g + 2)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g + 1 < GBHL / 8) DSS_GBL_GROUP(tB)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 {   // gates: lanes 0..15 z, 16..31 r, 32..47 h
@@ -362,6 +453,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                         L.state_b[lane] = zr * sb + (1 - zr) * h_for_z;
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
                 __syncthreads();                                                        // barrier D
@@ -422,12 +514,20 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
                               hipStream_t s)
 {
     if (!m.fast_ok || trace >= 16) return dss_launch_sample_network_generic(m, b, n_utts, n_frames, d_pcm, trace & 15, s);
+    const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
+    static bool attr_set = false;
+    if (!attr_set) {      // one workgroup uses (almost) the whole 160 KB of the CU
+        DSS_HIP_CHECK(hipFuncSetAttribute((const void *)lpcnet_sample_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES));
+        DSS_HIP_CHECK(hipFuncSetAttribute((const void *)lpcnet_sample_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES));
+        DSS_HIP_CHECK(hipFuncSetAttribute((const void *)lpcnet_sample_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES));
+        attr_set = true;
+    }
     if (trace == 2)        // diagnostic: phase stamps written into trace_pcm (never used for timing claims)
-        hipLaunchKernelGGL((lpcnet_sample_kernel<false, true>), dim3(n_utts), dim3(512), 0, s, m, b, n_frames, d_pcm);
+        hipLaunchKernelGGL((lpcnet_sample_kernel<false, true>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);
     else if (trace)
-        hipLaunchKernelGGL((lpcnet_sample_kernel<true, false>), dim3(n_utts), dim3(512), 0, s, m, b, n_frames, d_pcm);
+        hipLaunchKernelGGL((lpcnet_sample_kernel<true, false>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);
     else
-        hipLaunchKernelGGL((lpcnet_sample_kernel<false, false>), dim3(n_utts), dim3(512), 0, s, m, b, n_frames, d_pcm);
+        hipLaunchKernelGGL((lpcnet_sample_kernel<false, false>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }

@@ -16,7 +16,10 @@ SOURCES = ["dss_capi.cpp", "hga_kernels.hip", "lpcnet_frame.hip", "lpcnet_sample
 HEADERS = ["dss_common.h", "lpcnet_device.h", "../../include/dss_hip.h", "../../include/dss_lpcnet_blob.h"]
 # -ffp-contract=off: the path's parity contract is "same products, same sums, same order" as the scalar C
 # reference; a fused multiply-add anywhere would change results.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-x", "hip",
+# -fno-slp-vectorize: the hot loops are written with explicit 2-wide products where packing pays; automatic
+# packing of the scalar sum chains only adds register shuffles.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+         "-x", "hip",
          "-Wno-unused-result", "-Wno-unused-value"]
 
 

@@ -20,3 +20,13 @@ st = raw[: B * 6].reshape(B, 6) / n
 print("wave 7 (scalar role) view, cycles per sample, mean over utterances:")
 print("  " + "  ".join(f"{names[k]}={st[:, k].mean():8.1f}" for k in range(6)), " total", st.sum(axis=1).mean())
 print("  min/max total over utterances:", st.sum(axis=1).min(), st.sum(axis=1).max())
+rawA = np.empty((F * 160,), np.float32)
+chunks = []
+for k in range((B * 48 + rawA.size - 1) // rawA.size):
+    _lib.check(gpu._L.dss_lpcnet_batch_tap(gpu._h, k, 3, rawA.ctypes.data, rawA.size))
+    chunks.append(rawA.copy())
+sa = np.concatenate(chunks)[: B * 48].reshape(B, 6, 8) / n
+namesA = ["A->products", "emb wait+gz", "z/r sums", "activations", "wait B", "h chain", "wait C", "FC+wait D"]
+print("role A view (cycles per sample, mean over utterances), per wave:")
+for w in range(6):
+    print(f"  wave {w}: " + "  ".join(f"{namesA[k]}={sa[:, w, k].mean():7.1f}" for k in range(8)))
