@@ -1,0 +1,114 @@
+"""GPU tests of the unit surface and of the device-resident pipelines (configs 3 and 5)."""
+import asyncio
+
+import numpy as np
+import pytest
+import torch
+
+from dss_amd.lpcnet_weights import synthetic_blob, synthetic_features
+from dss_amd.synthetic import synthetic_ecog
+
+pytestmark = pytest.mark.gpu
+
+
+async def _drive(gen):
+    return [item async for item in gen]
+
+
+def test_high_gamma_activity_unit_matches_reference_golden(golden):
+    import local.units as U
+    g = golden("hga_frames.npz")
+    unit = U.HighGammaActivity(U.HighGammaActivitySettings(fs=1000, nb_electrodes=64))
+    unit.initialize()
+    x = synthetic_ecog(2000, 1040, 64)
+    frames = []
+    for i in range(0, 1040, 40):
+        (stream, msg), = asyncio.run(_drive(unit.process(U.ClosedLoopMessage(data=x[i:i + 40], fs=1000))))
+        assert stream is unit.OUTPUT and msg.fs == 100
+        frames.append(msg.data)
+    assert np.array_equal(np.concatenate(frames), g["online_out"])     # bit-identical to Cython + scipy
+
+
+def test_extractor_with_pre_and_post_transforms(golden):
+    """decode_online.py:65-97 wiring: 128-ch select -> CAR -> 64-ch select, then z-score after the log power."""
+    import local.units as U
+    from local.common import (CommonAverageReferencing, SelectElectrodesFromBothGrids, SelectElectrodesOverSpeechAreas,
+                              ZScoreNormalization)
+    both, speech = SelectElectrodesFromBothGrids(), SelectElectrodesOverSpeechAreas()
+    speech_grid = np.flip(np.arange(64, dtype=np.int16).reshape((8, 8)) + 1, axis=0)
+    motor_grid = np.flip(np.arange(64, dtype=np.int16).reshape((8, 8)) + 65, axis=0)
+    car = CommonAverageReferencing([19, 38, 48, 52], [speech_grid, motor_grid], np.arange(128) + 1)
+    post = ZScoreNormalization(np.full((1, 64), 3.0), np.full((1, 64), 2.0))
+    ex = U.HighGammaExtractor(1000, 64, pre_transforms=[both, car, speech], post_transforms=[post])
+    raw = synthetic_ecog(77, 200, 129)
+    got = ex.extract_features(raw)
+    plain = U.HighGammaExtractor(1000, 64).extract_features(speech(car(both(raw))))
+    assert got.shape == (16, 64) and np.array_equal(got, (plain - 3.0) / 2.0)
+
+
+def test_vocoder_unit_segments_and_state_carry(oracle):
+    import local.units as U
+    from dss_amd import lpcnet
+    blob = synthetic_blob(0)
+    lpcnet.load_model(blob)
+    voc = U.DelayedLPCNetVocoder()
+    voc.initialize()
+    dec = oracle.decoder(oracle.lpcnet_model(blob))
+    for seed, L in ((11, 9), (12, 5)):                         # two segments through ONE decoder state
+        seg = synthetic_features(seed, L).astype(np.float64)   # the unit casts to float32 itself (units.py:532)
+        (_, msg), = asyncio.run(_drive(voc.synthesize(U.ClosedLoopMessage(data=seg, fs=100))))
+        want = np.hstack([dec.synthesize(row) for row in seg.astype(np.float32)])
+        assert msg.fs == 16000 and msg.data.dtype == np.int16 and np.array_equal(msg.data, want)
+    voc.shutdown()
+
+
+def test_decoder_unit_on_gpu_matches_reference_golden(golden):
+    import local.units as U
+    from local.models import BidirectionalSpeechSynthesisModel
+    g = golden("models.npz")
+    torch.manual_seed(0)
+    unit = U.RecurrentNeuralDecodingModel(U.RecurrentNeuralDecodingModelSettings(
+        path_to_model_weights=None, model=BidirectionalSpeechSynthesisModel,
+        params=dict(nb_layer=2, nb_hidden_units=100, nb_electrodes=64)))
+    unit.initialize()
+    assert unit.STATE.device == "cuda"
+    (_, msg), = asyncio.run(_drive(unit.decode(U.ClosedLoopMessage(data=g["bilstm_in"][0], fs=100))))
+    np.testing.assert_allclose(msg.data, g["bilstm_out"][0], rtol=0, atol=2e-5)     # MIOpen LSTM vs CPU LSTM, fp32
+
+
+def test_segment_pipeline_config3(oracle, golden):
+    """64 segments of 1.04 s x 64 ch -> (64, 16000) PCM; every stage checked against its CPU counterpart."""
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import SegmentPipeline
+    blob = synthetic_blob(0)
+    lpcnet.load_model(blob)
+    B = 64
+    ecog = np.stack([synthetic_ecog(1000 + b, 1040, 64) for b in range(B)])
+    pipe = SegmentPipeline(B)
+    pcm, hga, feats = pipe(torch.from_numpy(ecog).cuda(), return_intermediates=True)
+    assert pcm.shape == (B, 16000) and hga.shape == (B, 100, 64) and feats.shape == (B, 100, 20)
+    g = golden("hga_frames.npz")
+    for b in range(4):                                         # HGA stage: device log, <= 1 ulp of the reference
+        want = g[f"offline{b}_out"]
+        assert (np.abs(hga[b].cpu().numpy() - want) / np.spacing(np.abs(want))).max() <= 1.0
+    # vocoder stage: bit-exact against the oracle fed the SAME device-produced features
+    m = oracle.lpcnet_model(blob)
+    f0 = feats[5].cpu().numpy()
+    assert np.array_equal(pcm[5].cpu().numpy(), oracle.lpcnet_utterance(m, f0))
+    # segments are independent: a second call reproduces the first
+    assert torch.equal(pipe(torch.from_numpy(ecog).cuda()), pcm)
+
+
+def test_streaming_pipeline_config5():
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import StreamingPipeline
+    lpcnet.load_model(synthetic_blob(0))
+    S = 128
+    sp = StreamingPipeline(S)
+    rng = np.random.default_rng(0)
+    first = sp.push(rng.standard_normal((S, 40, 64)) * 50)
+    assert first.shape == (S, 160)                             # warm-start frame buffer: 1 frame from packet 1
+    nxt = sp.push(rng.standard_normal((S, 40, 64)) * 50)
+    assert nxt.shape == (S, 640) and nxt.dtype == np.int16     # then 4 frames = 40 ms of audio per packet
+    lat = sp.measure_latency(20)
+    assert np.isfinite(lat).all() and np.percentile(lat, 50) < 40.0   # must keep up with the 40 ms packet cadence
