@@ -1,0 +1,66 @@
+"""Offline bulk synthesis with the file contract of the reference's ``AsynchronousSynthesisQueue``
+(local/training.py:165-207): every ``.npy`` file of LPCNet features (N x 20) becomes a 16 kHz ``.wav`` of the
+same name.  The reference forks a pool and runs one utterance per process on a fresh ``LPCNet()``; here the
+pending files are synthesised together, one persistent workgroup per utterance, in batched GPU launches.
+(The rest of the reference's training.py -- dataset, checkpointing -- is training code and out of scope.)"""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+from typing import List
+
+import numpy as np
+
+logger = logging.getLogger("training.py")
+
+
+class AsynchronousSynthesisQueue:
+    MAX_BATCH = 256
+
+    def __init__(self, nb_processes: int = 0):
+        # nb_processes is accepted for signature compatibility; parallelism comes from the GPU batch
+        self.nb_processes = nb_processes
+        self._pending: List[str] = []
+
+    def add_job(self, filename: str, verbose: int = 0):
+        if verbose > 0:
+            logger.info(f"Queued {filename} for synthesis.")
+        self._pending.append(filename)
+        if len(self._pending) >= self.MAX_BATCH:
+            self._flush()
+
+    def wait(self):
+        """Synthesize everything still pending (the reference closes and joins its pool here)."""
+        self._flush()
+
+    @staticmethod
+    def _generate_audio_from_lpc(lpc_filename: str, verbose: int = 0):
+        q = AsynchronousSynthesisQueue()
+        q.add_job(lpc_filename, verbose)
+        q.wait()
+
+    def _flush(self):
+        from scipy.io.wavfile import write as wavwrite
+        from dss_amd.lpcnet import LPCNetBatch
+        jobs, self._pending = self._pending, []
+        loaded = []
+        for name in jobs:
+            try:    # like the reference, a bad file is logged and skipped, never fatal (training.py:196-198)
+                feats = np.load(name).astype(np.float32)
+                if feats.ndim != 2 or feats.shape[1] < 20 or feats.shape[0] == 0:
+                    raise ValueError(f"expected (N, >=20) features, got {feats.shape}")
+                loaded.append((name, np.ascontiguousarray(feats[:, :20])))
+            except Exception as e:
+                logger.error(f"Could not synthesize {name} due to an unexpected exceptions: {str(e)}")
+        if not loaded:
+            return
+        loaded.sort(key=lambda it: it[1].shape[0])
+        for a in range(0, len(loaded), self.MAX_BATCH):
+            chunk = loaded[a:a + self.MAX_BATCH]
+            frames = max(f.shape[0] for _, f in chunk)
+            batch = np.zeros((len(chunk), frames, 20), dtype=np.float32)     # zero-padded tails are discarded:
+            for i, (_, f) in enumerate(chunk):                                 # synthesis is causal
+                batch[i, : f.shape[0]] = f
+            pcm = LPCNetBatch(len(chunk), frames).synthesize(batch)            # fresh decoder per utterance
+            for i, (name, f) in enumerate(chunk):
+                wavwrite(Path(name).with_suffix(".wav").as_posix(), 16000, pcm[i, : f.shape[0] * 160])

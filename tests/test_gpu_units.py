@@ -112,3 +112,25 @@ def test_streaming_pipeline_config5():
     assert nxt.shape == (S, 640) and nxt.dtype == np.int16     # then 4 frames = 40 ms of audio per packet
     lat = sp.measure_latency(20)
     assert np.isfinite(lat).all() and np.percentile(lat, 50) < 40.0   # must keep up with the 40 ms packet cadence
+
+
+def test_asynchronous_synthesis_queue_file_contract(tmp_path, oracle):
+    """.npy (N x 20) -> .wav 16 kHz, ragged lengths in one batch, bad files skipped."""
+    from scipy.io.wavfile import read as wavread
+    from dss_amd import lpcnet
+    from local.training import AsynchronousSynthesisQueue
+    blob = synthetic_blob(0)
+    lpcnet.load_model(blob)
+    m = oracle.lpcnet_model(blob)
+    lengths = {"a": 7, "b": 4, "c": 11}
+    for name, n in lengths.items():
+        np.save(tmp_path / f"{name}.npy", synthetic_features(ord(name), n).astype(np.float64))
+    np.save(tmp_path / "bad.npy", np.zeros((3, 5)))
+    q = AsynchronousSynthesisQueue(nb_processes=8)
+    for name in list(lengths) + ["bad", "missing"]:
+        q.add_job(str(tmp_path / f"{name}.npy"))
+    q.wait()
+    for name, n in lengths.items():
+        rate, pcm = wavread(tmp_path / f"{name}.wav")
+        assert rate == 16000 and np.array_equal(pcm, oracle.lpcnet_utterance(m, synthetic_features(ord(name), n)))
+    assert not (tmp_path / "bad.wav").exists()
