@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU (configs[1]: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the streaming-latency leg (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +149,7 @@ def main():
 
     # second half of BASELINE.json's metric: ECoG -> audio latency of the streaming mode (config 5), N=1 only
     latency = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_latency:
         from dss_amd.pipeline import StreamingPipeline
         sp = StreamingPipeline(128)
         sp.measure_latency(10)
@@ -158,6 +159,17 @@ def main():
                              "packet in -> HGA -> BiLSTM (chunk-wise, VAD gating off) -> LPCNet -> 640 int16 samples per "
                              "stream back on the host; structural floor of the reference (0.55 s + whole-segment "
                              "synthesis) not included"}
+
+    # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process, so the
+    # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/*_pmc_traffic.json),
+    # valid for the default workload only
+    traffic = None
+    try:
+        if B == 256:
+            with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
+                traffic = float(json.load(f)["hbm_bytes_per_launch_corrected"]) / 1e9      # GB per launch
+    except Exception:
+        traffic = None
 
     if rank == 0:
         samples_per_step = world * B * FRAMES * FRAME
@@ -176,7 +188,8 @@ def main():
                        "parallelism": f"utterance-sharded x{world}"},
             "x_realtime": value / 16000.0, "samples_per_s_per_gpu": value / world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/)",
+                         "algorithmic_GB_per_launch": alg_bytes_per_launch / 1e9,
                          "kernel": "lpcnet_sample_kernel", "kernel_ms": k_ms, "frame_kernels_ms": f_ms,
                          "algorithmic_bytes_per_sample": bps,
                          "note": "algorithmic bytes = weights touched once per output sample at fp32 (SURVEY 8d); they are "
