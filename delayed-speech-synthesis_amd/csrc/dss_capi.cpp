@@ -303,27 +303,34 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
             hmax = std::max(hmax, cnt[2 * G + g]);
         }
         if (zmax > DSS_ZRC || hmax > DSS_HC) fast_ok = 0;
-        // row groups sorted by h-gate block count: 8 consecutive groups share a wave, so each wave's h-gate
-        // loop length (its largest group) is close to what every group in it needs
-        std::vector<int> order(G);
-        for (int g = 0; g < G; ++g) order[g] = g;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return cnt[2 * G + a] > cnt[2 * G + b2]; });
-        // sorted rank -> wave: waves (0,4) and (1,5) share a SIMD, waves 2 and 3 share theirs with the GRU B
-        // relay waves, so pair the heaviest chunk with the lightest and give the middle ones to waves 2, 3
-        static const int rank_wave[6] = {0, 1, 2, 3, 5, 4};
-        std::vector<int> unit_of(NA, 0), wave_nh(8, 0), wave_hoff(8, 0), wave_nzr(8, 0), grp_of_slot(G, 0);
+        // Two independent lane assignments, both "8 row groups per wave":
+        //  * h-gate chains (LDS resident, run under GRU B): groups sorted by h block count, so each wave's loop
+        //    length (its largest group) is close to what all its groups need and the LDS image stays small;
+        //    sorted rank -> wave {0,1,2,3,5,4}: waves (0,4) and (1,5) share a SIMD -> heaviest with lightest.
+        //  * z/r chains (register resident, on the critical path): groups sorted by max(z, r) block count; the
+        //    two heaviest chunks go to waves 2 and 3, which have their SIMD to themselves in that phase (their
+        //    partners 6 and 7 are idle), the lighter ones are paired on the shared SIMDs.
+        // The per-unit pre-activation of the h gate travels from its h lane to its z/r lane through LDS.
+        std::vector<int> order_h(G), order_zr(G);
+        for (int g = 0; g < G; ++g) order_h[g] = order_zr[g] = g;
+        std::stable_sort(order_h.begin(), order_h.end(), [&](int a, int b2) { return cnt[2 * G + a] > cnt[2 * G + b2]; });
+        std::stable_sort(order_zr.begin(), order_zr.end(), [&](int a, int b2) {
+            return std::max(cnt[a], cnt[G + a]) > std::max(cnt[b2], cnt[G + b2]);
+        });
+        static const int rank_wave_h[6] = {0, 1, 2, 3, 5, 4};
+        static const int rank_wave_zr[6] = {2, 3, 0, 1, 5, 4};
+        std::vector<int> unit_of(NA, 0), unit_h(NA, 0), wave_nh(8, 0), wave_hoff(8, 0), wave_nzr(8, 0), grp_h(G, 0), grp_zr(G, 0);
         int hfloats = 0;
         for (int rk = 0; rk < 6 && fast_ok; ++rk) {
-            const int wv = rank_wave[rk];
             int nh = 0, nzr = 0;
             for (int q = 0; q < 8; ++q) {
-                const int grp = order[rk * 8 + q];
-                grp_of_slot[wv * 8 + q] = grp;
-                nh = std::max(nh, cnt[2 * G + grp]);
-                nzr = std::max(nzr, std::max(cnt[grp], cnt[G + grp]));
+                grp_h[rank_wave_h[rk] * 8 + q] = order_h[rk * 8 + q];
+                grp_zr[rank_wave_zr[rk] * 8 + q] = order_zr[rk * 8 + q];
+                nh = std::max(nh, cnt[2 * G + order_h[rk * 8 + q]]);
+                nzr = std::max(nzr, std::max(cnt[order_zr[rk * 8 + q]], cnt[G + order_zr[rk * 8 + q]]));
             }
-            wave_nh[wv] = (nh + 1) & ~1;            // the kernel tests for the end of a list every 2 slots
-            wave_nzr[wv] = (nzr + 1) & ~1;
+            wave_nh[rank_wave_h[rk]] = (nh + 1) & ~1;       // the kernel tests for the end of a list every 2 slots
+            wave_nzr[rank_wave_zr[rk]] = (nzr + 1) & ~1;
         }
         for (int wv = 0; wv < 6 && fast_ok; ++wv) {
             wave_hoff[wv] = hfloats;
@@ -336,23 +343,29 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         std::vector<unsigned> zr_col((size_t)(2 * DSS_ZRC / 4) * NA, 0u), h_col((size_t)(DSS_HC / 4) * NA, 0u);
         if (fast_ok)
             for (int tid = 0; tid < NA; ++tid) {
-                const int wv = tid / 64, l = tid & 63, q = l / 8, r = l & 7, grp = grp_of_slot[wv * 8 + q];
-                unit_of[tid] = grp * 8 + r;
-                for (int gate = 0; gate < 2; ++gate) {
-                    const int g = gate * G + grp;
-                    for (int sl = 0; sl < cnt[g]; ++sl) {
-                        const int s2 = gate * DSS_ZRC + sl;
-                        const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                        for (int k = 0; k < 4; ++k) zr_w[((size_t)s2 * 4 + k) * NA + tid] = wb[k * 8 + r];
-                        zr_col[(size_t)(s2 >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (s2 & 3));
+                const int wv = tid / 64, l = tid & 63, q = l / 8, r = l & 7;
+                {
+                    const int grp = grp_zr[wv * 8 + q];
+                    unit_of[tid] = grp * 8 + r;
+                    for (int gate = 0; gate < 2; ++gate) {
+                        const int g = gate * G + grp;
+                        for (int sl = 0; sl < cnt[g]; ++sl) {
+                            const int s2 = gate * DSS_ZRC + sl;
+                            const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                            for (int k = 0; k < 4; ++k) zr_w[((size_t)s2 * 4 + k) * NA + tid] = wb[k * 8 + r];
+                            zr_col[(size_t)(s2 >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (s2 & 3));
+                        }
                     }
                 }
-                const int g = 2 * G + grp;
-                for (int sl = 0; sl < cnt[g]; ++sl) {
-                    const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                    float *rec = hblk.data() + wave_hoff[wv] + ((size_t)q * (wave_nh[wv] + 1) + sl) * 32 + r * 4;
-                    for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
-                    h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
+                {
+                    const int grp = grp_h[wv * 8 + q], g = 2 * G + grp;
+                    unit_h[tid] = grp * 8 + r;
+                    for (int sl = 0; sl < cnt[g]; ++sl) {
+                        const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                        float *rec = hblk.data() + wave_hoff[wv] + ((size_t)q * (wave_nh[wv] + 1) + sl) * 32 + r * 4;
+                        for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
+                        h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
+                    }
                 }
             }
         m.fast_ok = fast_ok;
@@ -360,6 +373,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         m.hblk_floats = hfloats;
         int *di; float *df; unsigned *du;
         rc = dev_upload<int>(unit_of.data(), unit_of.size(), &di); if (rc) return rc; m.unit_of = di;
+        rc = dev_upload<int>(unit_h.data(), unit_h.size(), &di); if (rc) return rc; m.unit_h = di;
         rc = dev_upload<int>(wave_nh.data(), wave_nh.size(), &di); if (rc) return rc; m.wave_nh = di;
         rc = dev_upload<int>(wave_hoff.data(), wave_hoff.size(), &di); if (rc) return rc; m.wave_hoff = di;
         rc = dev_upload<int>(wave_nzr.data(), wave_nzr.size(), &di); if (rc) return rc; m.wave_nzr = di;

@@ -24,7 +24,7 @@
 // (or whose h-gate block image does not fit DSS_HBLK_BYTES of LDS) runs on the generic kernel instead.
 #define DSS_ZRC 12            // register slots per lane for the z-gate and for the r-gate 8x4 blocks
 #define DSS_HC 28             // max h-gate blocks per row group (LDS resident; column ids in 7 VGPRs)
-#define DSS_HBLK_BYTES 140000  // dynamic LDS left after the kernel's static 22.3 KB (160 KB per CU)
+#define DSS_HBLK_BYTES 139264  // dynamic LDS left after the kernel's static 24 KB (160 KB per CU)
 
 void dss_set_error(const char *fmt, ...);
 
@@ -70,7 +70,8 @@ struct DssModelDev {
     int fast_ok;                  // 1 when the model fits the capacities above
     int nzr_max;                  // max(z blocks, r blocks) over all row groups, rounded up to even
     int hblk_floats;              // size of hblk
-    const int *unit_of;           // [384] lane of waves 0..5 -> GRU A unit (row groups sorted by h block count)
+    const int *unit_of;           // [384] lane of waves 0..5 -> GRU A unit whose z and r chains it runs
+    const int *unit_h;            // [384] lane of waves 0..5 -> GRU A unit whose h-gate chain it runs
     const int *wave_nh;           // [8]   per wave: h-gate slots (even), [6],[7] unused
     const int *wave_hoff;         // [8]   per wave: float offset of its block records inside hblk
     const int *wave_nzr;          // [8]   per wave: z/r slots actually used (even)

@@ -45,6 +45,7 @@ struct SampleLds {
     float ulaw2lin[256];
     float logit_table[256];
     float gb_acc[64];                     // GRU B partial sums handed from wave 6 to wave 7
+    float ah[NA];                         // h-gate pre-activation: written by a unit's h lane, read by its z/r lane
     float state_b[NB];
     float thr[8];
     unsigned bits[8];                     // decision bit of every tree node (256 bits)
@@ -99,7 +100,7 @@ struct SampleLds {
     {                                                                                            \
         const char *xbase = reinterpret_cast<const char *>(XBUF);                                \
         f32x4 HA[4], HB[4];                                                                      \
-        ah = rbh + dgh * st;                                                                     \
+        float ah = rbh + dgh * (XBUF)[uh];                                                       \
         DSS_H_LOAD(HA, 0)                                                                        \
         _Pragma("unroll") for (int c = 0; c < HC / 2; c += 2) {                                  \
             if (2 * c >= nh) break;                                                              \
@@ -113,6 +114,7 @@ struct SampleLds {
             DSS_H_MAC(HB)                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
+        L.ah[uh] = ah;                                                                           \
     }
 // N inputs (multiple of 16) of the GRU B chain of one row.  Weights come from this lane's registers, the new
 // GRU A state from LDS (same address in every lane -> broadcast), fetched one group of 16 inputs ahead so the
@@ -196,7 +198,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         // =====================================================================================================
         // role A: GRU A (+ dual-FC on waves 0..3)
         // =====================================================================================================
-        const int unit = m.unit_of[tid];
+        const int unit = m.unit_of[tid];                             // z/r chains + gates of this unit
+        const int uh = m.unit_h[tid];                                // h-gate chain of this (other) unit
         const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
         const int nzr = __builtin_amdgcn_readfirstlane(m.wave_nzr[wave]);
         const char *hw = reinterpret_cast<const char *>(hblk_lds + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
@@ -214,8 +217,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         for (int s = 0; s < 2 * ZRC / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
 #pragma unroll
         for (int s = 0; s < HC / 4; ++s) PH[s] = m.h_col[(size_t)s * NA + tid];
-        const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + unit];
-        const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + unit];
+        const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + uh];
+        const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + uh];
         // dual-FC constants of tree node `tid` (waves 0..3)
         float fw0[NB], fw1[NB], fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
         {
@@ -231,7 +234,6 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
         int cur = 0;
         float st = L.state_a[0][unit];
-        float ah;
         unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
         DSS_H_CHAIN(L.state_a[0])                                    // first sample of this call
 
@@ -291,7 +293,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
                     const float z = dss_sigmoid_approx(L.tansig, az);
                     const float r = dss_sigmoid_approx(L.tansig, ar);
-                    float h = ah * r + gh;
+                    float h = L.ah[unit] * r + gh;
                     h = dss_tanh_approx(L.tansig, h);
                     st = z * st + (1 - z) * h;
                     L.state_a[cur ^ 1][unit] = st;
@@ -300,7 +302,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
                 DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
-                if (STAMP) { asm volatile("" :: "v"(ah)); unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
                 if (tid < DSS_FC_OUT) {                                                 // sample_mdense, all nodes
