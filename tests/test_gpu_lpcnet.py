@@ -134,3 +134,43 @@ def test_full_size_batch_256_properties(golden, model):
     pcm2 = gpu.synthesize_torch(d).cpu().numpy()                 # device-resident entry point, permuted slots
     assert np.array_equal(pcm2, pcm[perm])
     assert (pcm[:, :320] == 0).all() and np.abs(pcm[:, 320:]).max() > 1000
+
+
+def _oracle_pcm(oracle, blob, feats):
+    m = oracle.lpcnet_model(blob)
+    return np.stack([oracle.lpcnet_utterance(m, f) for f in feats])
+
+
+def test_other_sparsity_patterns_and_generic_fallback(oracle):
+    """Models with different block-sparsity patterns: seed 1 has row groups with 11-12 z/r blocks (the register
+    slot capacity), a denser model exceeds the CU-resident kernel's capacities and must run on the generic
+    kernel -- all bit-exact.  Also forces the generic kernel on the default model."""
+    from dss_amd import lpcnet
+    from dss_amd.lpcnet import LPCNetBatch
+    from dss_amd.lpcnet_weights import make_synthetic_weights, pack_blob
+    feats = np.stack([synthetic_features(700 + b, 6) for b in range(3)])
+    try:
+        for seed, density in ((1, (0.05, 0.05, 0.20)), (2, (0.05, 0.05, 0.20)), (3, (0.12, 0.10, 0.30))):
+            blob = pack_blob(make_synthetic_weights(seed, density=density))
+            lpcnet.load_model(blob)
+            got = LPCNetBatch(3, 6).synthesize(feats)
+            assert np.array_equal(got, _oracle_pcm(oracle, blob, feats)), (seed, density)
+        blob = synthetic_blob(0)
+        lpcnet.load_model(blob)
+        gen = LPCNetBatch(3, 6)
+        gen.enable_trace(16)                                   # development switch: force the generic kernel
+        assert np.array_equal(gen.synthesize(feats), _oracle_pcm(oracle, blob, feats))
+    finally:
+        lpcnet.load_model(synthetic_blob(0))
+
+
+def test_batch_larger_than_the_chip(golden, model):
+    """More utterances than CUs (config 4's per-GPU share is 1024): workgroups run in several rounds."""
+    from dss_amd.lpcnet import LPCNetBatch
+    g = golden("lpcnet_self.npz")
+    B, F = 600, 30
+    feats = np.stack([synthetic_features(2, F)] * B)
+    feats[1::2] = synthetic_features(5, F)
+    pcm = LPCNetBatch(B, F).synthesize(feats)
+    assert np.array_equal(pcm[0], g["utt2_pcm"]) and np.array_equal(pcm[598], g["utt2_pcm"])
+    assert (pcm[1::2] == pcm[1]).all() and not np.array_equal(pcm[0], pcm[1])
