@@ -304,12 +304,14 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         }
         if (zmax > DSS_ZRC || hmax > DSS_HC) fast_ok = 0;
         // Two independent lane assignments, both "8 row groups per wave":
-        //  * h-gate chains (LDS resident, run under GRU B): groups sorted by h block count, so each wave's loop
-        //    length (its largest group) is close to what all its groups need and the LDS image stays small;
-        //    sorted rank -> wave {0,1,2,3,5,4}: waves (0,4) and (1,5) share a SIMD -> heaviest with lightest.
-        //  * z/r chains (register resident, on the critical path): groups sorted by max(z, r) block count; the
-        //    two heaviest chunks go to waves 2 and 3, which have their SIMD to themselves in that phase (their
-        //    partners 6 and 7 are idle), the lighter ones are paired on the shared SIMDs.
+        //  * h-gate chains (LDS resident): groups sorted by h block count, so each wave's loop length (its
+        //    largest group) is close to what all its groups need and the LDS image stays small;
+        //  * z/r chains (register resident): groups sorted by max(z, r) block count.
+        // Both the h chain and the z/r block products run between barriers B and C, under the GRU B relay.
+        // The z/r ranking is dealt in the opposite order of the h ranking, so every wave's total (h chain + z/r
+        // products) is about the same; waves 2 and 3, which share their SIMD with the two high-priority relay
+        // waves, get the lightest h chains and therefore the heaviest z/r chunks -- whose sums they then run
+        // between barriers A and B, when they have their SIMD to themselves.
         // The per-unit pre-activation of the h gate travels from its h lane to its z/r lane through LDS.
         std::vector<int> order_h(G), order_zr(G);
         for (int g = 0; g < G; ++g) order_h[g] = order_zr[g] = g;
@@ -317,8 +319,8 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         std::stable_sort(order_zr.begin(), order_zr.end(), [&](int a, int b2) {
             return std::max(cnt[a], cnt[G + a]) > std::max(cnt[b2], cnt[G + b2]);
         });
-        static const int rank_wave_h[6] = {0, 1, 2, 3, 5, 4};
-        static const int rank_wave_zr[6] = {2, 3, 0, 1, 5, 4};
+        static const int rank_wave_h[6] = {0, 1, 4, 5, 2, 3};
+        static const int rank_wave_zr[6] = {3, 2, 5, 4, 1, 0};
         std::vector<int> unit_of(NA, 0), unit_h(NA, 0), wave_nh(8, 0), wave_hoff(8, 0), wave_nzr(8, 0), grp_h(G, 0), grp_zr(G, 0);
         int hfloats = 0;
         for (int rk = 0; rk < 6 && fast_ok; ++rk) {

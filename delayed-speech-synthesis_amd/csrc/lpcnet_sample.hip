@@ -79,6 +79,20 @@ struct SampleLds {
         az += Q[1].x; ar += Q[3].x; az += Q[1].y; ar += Q[3].y;                                  \
         az += Q[1].z; ar += Q[3].z; az += Q[1].w; ar += Q[3].w;                                  \
     }
+// z/r block products of one lane for the coming sample: state vectors from LDS, weights from registers
+#define DSS_ZR_PRODUCTS(XBUF)                                                                    \
+    {                                                                                            \
+        const char *xb = reinterpret_cast<const char *>(XBUF);                                   \
+        _Pragma("unroll") for (int s2 = 0; s2 < ZRC; s2 += 2) {                                  \
+            if (s2 >= nzr) break;                                                                \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                      \
+                const f32x4 xz = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(s2 + u) * 16); \
+                const f32x4 xr = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(ZRC + s2 + u) * 16); \
+                PR[s2 + u].lo = WZ[s2 + u].lo * xz.lo;             PR[s2 + u].hi = WZ[s2 + u].hi * xz.hi;             \
+                PR[ZRC + s2 + u].lo = WZ[ZRC + s2 + u].lo * xr.lo; PR[ZRC + s2 + u].hi = WZ[ZRC + s2 + u].hi * xr.hi; \
+            }                                                                                    \
+        }                                                                                        \
+    }
 // h-gate chain of one lane: rbh + dgh*st, then its row group's blocks in idx order.  Chunk C = slots 2C, 2C+1;
 // block records (LDS) and state vectors of the next chunk are fetched while the current chunk's sums run.
 #define DSS_H_COL(S) ((PH[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu)
@@ -204,8 +218,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         const int nzr = __builtin_amdgcn_readfirstlane(m.wave_nzr[wave]);
         const char *hw = reinterpret_cast<const char *>(hblk_lds + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
                          ((lane >> 3) * (nh + 1) * 128 + (lane & 7) * 16);
-        f32x4 WZ[2 * ZRC];
-        unsigned PZ[2 * ZRC / 4], PH[HC / 4];
+        f32x4 WZ[2 * ZRC];                                           // [0,ZRC) z slots, [ZRC,2ZRC) r slots
+        unsigned PZ[(2 * ZRC + 3) / 4], PH[HC / 4];
 #pragma unroll
         for (int s = 0; s < 2 * ZRC; ++s) {
             WZ[s].x = m.zr_w[((size_t)s * 4 + 0) * NA + tid];
@@ -214,20 +228,18 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             WZ[s].w = m.zr_w[((size_t)s * 4 + 3) * NA + tid];
         }
 #pragma unroll
-        for (int s = 0; s < 2 * ZRC / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
+        for (int s = 0; s < (2 * ZRC + 3) / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
 #pragma unroll
         for (int s = 0; s < HC / 4; ++s) PH[s] = m.h_col[(size_t)s * NA + tid];
         const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + uh];
         const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + uh];
         // dual-FC constants of tree node `tid` (waves 0..3)
-        float fw0[NB], fw1[NB], fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
+        f32x4 fw[2 * NB / 4];
+        float fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
         {
             const int node = tid < DSS_FC_OUT ? tid : 0;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                fw0[j] = m.fc_w[(size_t)node * 2 * NB + j];
-                fw1[j] = m.fc_w[(size_t)node * 2 * NB + NB + j];
-            }
+            for (int k = 0; k < 2 * NB / 4; ++k) fw[k] = *reinterpret_cast<const f32x4 *>(m.fc_w + (size_t)node * 2 * NB + 4 * k);
             fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
             ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
         }
@@ -235,41 +247,37 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         int cur = 0;
         float st = L.state_a[0][unit];
         unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
+        f32x4 PR[2 * ZRC];                                           // z/r block products of the coming sample
         DSS_H_CHAIN(L.state_a[0])                                    // first sample of this call
+        DSS_ZR_PRODUCTS(L.state_a[0])
+        __syncthreads();                                             // L.ah of every unit visible to its z/r lane
 
         for (int f = 0; f < n_frames; ++f) {
             if (fc0 + f < DSS_FEATURES_DELAY) continue;              // silent frame: decoder state untouched
-            const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;
-            const float cz = fo[unit], cr = fo[NA + unit], ch = fo[2 * NA + unit];
+            const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;     // wave-uniform base
+            const float cz = fo[(unsigned)unit], cr = fo[(unsigned)(NA + unit)], ch = fo[(unsigned)(2 * NA + unit)];
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
                 // keep the packed column ids opaque so the per-slot unpacking is not hoisted out of the sample
                 // loop into (spilled) registers
 #pragma unroll
-                for (int k = 0; k < 2 * ZRC / 4; ++k) asm volatile("" : "+v"(PZ[k]));
+                for (int k = 0; k < (2 * ZRC + 3) / 4; ++k) asm volatile("" : "+v"(PZ[k]));
 #pragma unroll
                 for (int k = 0; k < HC / 4; ++k) asm volatile("" : "+v"(PH[k]));
                 float az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
                 float ar = rbr + dgr * st;
+                const float ahv = L.ah[unit];                        // this unit's h-gate pre-activation (its h lane, B..C)
                 __syncthreads();                                                        // barrier A
                 if (STAMP) ta = __builtin_readcyclecounter();
                 {
                     const int si = L.idx[0], pi = L.idx[1], ei = L.idx[2];
-                    const float *es = m.embed_sig + (size_t)si * 3 * NA + unit;
-                    const float *ep = m.embed_pred + (size_t)pi * 3 * NA + unit;
-                    const float *ee = m.embed_exc + (size_t)ei * 3 * NA + unit;
-                    // the nine embedding values of this lane: loads issued here, consumed after the first products
-                    const float es0 = es[0], es1 = es[NA], es2 = es[2 * NA];
-                    const float ep0 = ep[0], ep1 = ep[NA], ep2 = ep[2 * NA];
-                    const float ee0 = ee[0], ee1 = ee[NA], ee2 = ee[2 * NA];
-                    // z and r chains, two slots of each per chunk, two in-place buffers: a chunk's state reads and
-                    // products (independent of the embedding rows) are issued while the other chunk's dependent
-                    // sums run, and the first two chunks' in the shadow of the embedding loads.
-                    const char *xbase = reinterpret_cast<const char *>(L.state_a[cur]);
-                    f32x4 QA[4], QB[4];
-                    DSS_ZR_LOADX(QA, 0)
-                    if (2 < nzr) DSS_ZR_LOADX(QB, 1)
-                    DSS_ZR_MUL(QA, 0)
-                    __builtin_amdgcn_sched_barrier(0);
+                    // 32-bit element offsets from the (scalar) table bases: no 64-bit per-lane pointers to keep alive
+                    const unsigned so = (unsigned)si * (3 * NA) + (unsigned)unit;
+                    const unsigned po = (unsigned)pi * (3 * NA) + (unsigned)unit;
+                    const unsigned eo = (unsigned)ei * (3 * NA) + (unsigned)unit;
+                    // the nine embedding values of this lane
+                    const float es0 = m.embed_sig[so], es1 = m.embed_sig[so + NA], es2 = m.embed_sig[so + 2 * NA];
+                    const float ep0 = m.embed_pred[po], ep1 = m.embed_pred[po + NA], ep2 = m.embed_pred[po + 2 * NA];
+                    const float ee0 = m.embed_exc[eo], ee1 = m.embed_exc[eo + NA], ee2 = m.embed_exc[eo + 2 * NA];
                     if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[0] += t - ta; ta = t; }
                     const float gz = ((cz + es0) + ep0) + ee0;                          // compute_gru_a_input
                     const float gr = ((cr + es1) + ep1) + ee1;
@@ -277,23 +285,23 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     az = az + gz;                       // (bias + diag*state) + input, then the blocks in idx order
                     ar = ar + gr;
                     if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[1] += t - ta; ta = t; }
+                    // the block products were formed right after the previous sample's state update (under GRU B);
+                    // what is left on the critical path are the dependent sums, z and r chains interleaved
 #pragma unroll
-                    for (int c = 0; c < ZRC / 2; c += 2) {
-                        if (2 * c >= nzr) break;
-                        if (2 * (c + 1) < nzr) DSS_ZR_MUL(QB, c + 1)
-                        DSS_ZR_ADD(QA)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (2 * (c + 2) < nzr) DSS_ZR_LOADX(QA, c + 2)
-                        if (2 * (c + 1) >= nzr) break;
-                        DSS_ZR_ADD(QB)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (2 * (c + 3) < nzr) DSS_ZR_LOADX(QB, c + 3)
-                        if (2 * (c + 2) < nzr) DSS_ZR_MUL(QA, c + 2)
+                    for (int s2 = 0; s2 < ZRC; s2 += 2) {
+                        if (s2 >= nzr) break;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            az += PR[s2 + u].x; ar += PR[ZRC + s2 + u].x;
+                            az += PR[s2 + u].y; ar += PR[ZRC + s2 + u].y;
+                            az += PR[s2 + u].z; ar += PR[ZRC + s2 + u].z;
+                            az += PR[s2 + u].w; ar += PR[ZRC + s2 + u].w;
+                        }
                     }
                     if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
                     const float z = dss_sigmoid_approx(L.tansig, az);
                     const float r = dss_sigmoid_approx(L.tansig, ar);
-                    float h = L.ah[unit] * r + gh;
+                    float h = ahv * r + gh;
                     h = dss_tanh_approx(L.tansig, h);
                     st = z * st + (1 - z) * h;
                     L.state_a[cur ^ 1][unit] = st;
@@ -302,16 +310,20 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
                 DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
+                DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
                 if (tid < DSS_FC_OUT) {                                                 // sample_mdense, all nodes
                     float s1 = fb0, s2 = fb1;
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-                        const float bj = L.state_b[j];
-                        s1 += fw0[j] * bj;
-                        s2 += fw1[j] * bj;
+                    for (int j4 = 0; j4 < NB / 4; ++j4) {
+                        const f32x4 bj = *reinterpret_cast<const f32x4 *>(L.state_b + 4 * j4);
+                        const f32x4 w0 = fw[j4], w1 = fw[NB / 4 + j4];
+                        s1 += w0.x * bj.x; s2 += w1.x * bj.x;
+                        s1 += w0.y * bj.y; s2 += w1.y * bj.y;
+                        s1 += w0.z * bj.z; s2 += w1.z * bj.z;
+                        s1 += w0.w * bj.w; s2 += w1.w * bj.w;
                     }
                     s1 = ff0 * dss_tanh_approx(L.tansig, s1);
                     s2 = ff1 * dss_tanh_approx(L.tansig, s2);
@@ -340,8 +352,10 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             WB[j].y = m.gb_w_lane[(size_t)(2 * j + 1) * 64 + lane];
         }
         const int row = lane < NB3 ? lane : 0;
+        __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
         const float gbb0 = m.gru_b_bias[row];
         int cur = 0, seq = 0;
+        __syncthreads();                                             // matches role A's prologue barrier
         for (int f = 0; f < n_frames; ++f) {
             if (fc0 + f < DSS_FEATURES_DELAY) continue;
             const float gbc = b.frame_out[((size_t)utt * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row];
@@ -351,9 +365,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 __syncthreads();                                                        // barrier A
                 __syncthreads();                                                        // barrier B
                 const float *an = L.state_a[cur ^ 1];
-                __builtin_amdgcn_s_setprio(3);            // the sample's critical chain: win VALU arbitration
                 DSS_GB_CHAIN(an, GBH6)
-                __builtin_amdgcn_s_setprio(0);
                 L.gb_acc[lane] = acc;
                 __hip_atomic_store(&L.gb_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __syncthreads();                                                        // barrier C
@@ -373,6 +385,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             WB[j].y = m.gb_w_lane[(size_t)(GBH6 + 2 * j + 1) * 64 + lane];
         }
         const int row = lane < NB3 ? lane : 0;
+        __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
         const float gbb1 = m.gru_b_bias[NB3 + row];
         float last_sig[DSS_LPC_ORDER], lpc[DSS_LPC_ORDER];
 #pragma unroll
@@ -383,6 +396,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long t_prev = 0;
         int cur = 0, seq = 0;
+        __syncthreads();                                             // matches role A's prologue barrier
         for (int f = 0; f < n_frames; ++f) {
             short *pcm_frame = pcm_out + ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE;
             if (fc0 + f < DSS_FEATURES_DELAY) {             // lpcnet.c: frame_count <= FEATURES_DELAY -> silence
@@ -425,7 +439,6 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
                     __builtin_amdgcn_s_sleep(1);
                 float acc = L.gb_acc[lane];
-                __builtin_amdgcn_s_setprio(3);
                 {
                     const float *an = L.state_a[cur ^ 1] + GBH6;
                     DSS_GB_CHAIN(an, GBH7)
@@ -455,7 +468,6 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                         L.state_b[lane] = zr * sb + (1 - zr) * h_for_z;
                     }
                 }
-                __builtin_amdgcn_s_setprio(0);
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
                 __syncthreads();                                                        // barrier D
