@@ -28,7 +28,8 @@
 #define NA DSS_GRU_A
 #define NB DSS_GRU_B
 #define NB3 (3 * DSS_GRU_B)
-#define ZRC DSS_ZRC
+#define ZRC Z                             // template parameter: z/r register slots per gate (10 or 12)
+#define ZRL DSS_ZRC                       // slot stride of the host layout (zr_w, zr_col)
 #define HC DSS_HC
 #define GBH6 208                          // GRU B inputs whose weights sit in wave 6's VGPRs (0..207)
 #define GBH7 112                          // ... in wave 7's VGPRs (208..319); wave 7 also carries the scalar state
@@ -57,7 +58,7 @@ struct SampleLds {
 
 // one 8x4 block applied to one row: four products accumulated one at a time (sparse_sgemv_accum8x4 order)
 // z/r chunk C = slots 2C, 2C+1 of the z list and of the r list (Q[0..1] z, Q[2..3] r)
-#define DSS_ZR_COL(S) ((PZ[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu)
+#define DSS_ZR_COL(S) ((PZ[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu)      /* S in layout numbering: z s, r ZRL + s */
 #define DSS_ZR_LOADX(Q, C)                                                                       \
     {                                                                                            \
         Q[0] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(2 * (C)) * 16);               \
@@ -87,7 +88,7 @@ struct SampleLds {
             if (s2 >= nzr) break;                                                                \
             _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                      \
                 const f32x4 xz = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(s2 + u) * 16); \
-                const f32x4 xr = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(ZRC + s2 + u) * 16); \
+                const f32x4 xr = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(ZRL + s2 + u) * 16); \
                 PR[s2 + u].lo = WZ[s2 + u].lo * xz.lo;             PR[s2 + u].hi = WZ[s2 + u].hi * xz.hi;             \
                 PR[ZRC + s2 + u].lo = WZ[ZRC + s2 + u].lo * xr.lo; PR[ZRC + s2 + u].hi = WZ[ZRC + s2 + u].hi * xr.hi; \
             }                                                                                    \
@@ -180,7 +181,7 @@ struct SampleLds {
         acc += p1.y;                                                                             \
     }
 
-template <bool TRACE, bool STAMP>
+template <bool TRACE, bool STAMP, int Z>
 __global__ void __launch_bounds__(512)
 lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restrict__ pcm_out)
 {
@@ -219,16 +220,17 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         const char *hw = reinterpret_cast<const char *>(hblk_lds + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
                          ((lane >> 3) * (nh + 1) * 128 + (lane & 7) * 16);
         f32x4 WZ[2 * ZRC];                                           // [0,ZRC) z slots, [ZRC,2ZRC) r slots
-        unsigned PZ[(2 * ZRC + 3) / 4], PH[HC / 4];
+        unsigned PZ[(2 * ZRL + 3) / 4], PH[HC / 4];
 #pragma unroll
         for (int s = 0; s < 2 * ZRC; ++s) {
-            WZ[s].x = m.zr_w[((size_t)s * 4 + 0) * NA + tid];
-            WZ[s].y = m.zr_w[((size_t)s * 4 + 1) * NA + tid];
-            WZ[s].z = m.zr_w[((size_t)s * 4 + 2) * NA + tid];
-            WZ[s].w = m.zr_w[((size_t)s * 4 + 3) * NA + tid];
+            const int slot = s < ZRC ? s : ZRL + (s - ZRC);          // layout numbering
+            WZ[s].x = m.zr_w[((size_t)slot * 4 + 0) * NA + tid];
+            WZ[s].y = m.zr_w[((size_t)slot * 4 + 1) * NA + tid];
+            WZ[s].z = m.zr_w[((size_t)slot * 4 + 2) * NA + tid];
+            WZ[s].w = m.zr_w[((size_t)slot * 4 + 3) * NA + tid];
         }
 #pragma unroll
-        for (int s = 0; s < (2 * ZRC + 3) / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
+        for (int s = 0; s < (2 * ZRL + 3) / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
 #pragma unroll
         for (int s = 0; s < HC / 4; ++s) PH[s] = m.h_col[(size_t)s * NA + tid];
         const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + uh];
@@ -260,7 +262,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 // keep the packed column ids opaque so the per-slot unpacking is not hoisted out of the sample
                 // loop into (spilled) registers
 #pragma unroll
-                for (int k = 0; k < (2 * ZRC + 3) / 4; ++k) asm volatile("" : "+v"(PZ[k]));
+                for (int k = 0; k < (2 * ZRL + 3) / 4; ++k) asm volatile("" : "+v"(PZ[k]));
 #pragma unroll
                 for (int k = 0; k < HC / 4; ++k) asm volatile("" : "+v"(PH[k]));
                 float az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
@@ -529,19 +531,26 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
 {
     if (!m.fast_ok || trace >= 16) return dss_launch_sample_network_generic(m, b, n_utts, n_frames, d_pcm, trace & 15, s);
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
+    // two register-slot capacities are compiled: 10 per gate (no spills) and 12 (a few spilled registers)
+    const bool z10 = m.nzr_max <= 10;
     static bool attr_set = false;
     if (!attr_set) {      // one workgroup uses (almost) the whole 160 KB of the CU
-        DSS_HIP_CHECK(hipFuncSetAttribute((const void *)lpcnet_sample_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES));
-        DSS_HIP_CHECK(hipFuncSetAttribute((const void *)lpcnet_sample_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES));
-        DSS_HIP_CHECK(hipFuncSetAttribute((const void *)lpcnet_sample_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES));
+#define DSS_SET_ATTR(K) DSS_HIP_CHECK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES))
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10>)); DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 10>));  DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 12>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 10>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 12>));
+#undef DSS_SET_ATTR
         attr_set = true;
     }
-    if (trace == 2)        // diagnostic: phase stamps written into trace_pcm (never used for timing claims)
-        hipLaunchKernelGGL((lpcnet_sample_kernel<false, true>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);
-    else if (trace)
-        hipLaunchKernelGGL((lpcnet_sample_kernel<true, false>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);
-    else
-        hipLaunchKernelGGL((lpcnet_sample_kernel<false, false>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);
+#define DSS_LAUNCH(T, S2)                                                                                              \
+    do {                                                                                                               \
+        if (z10) hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 10>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm); \
+        else hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 12>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);     \
+    } while (0)
+    if (trace == 2) DSS_LAUNCH(false, true);        // diagnostic: phase stamps (never used for timing claims)
+    else if (trace) DSS_LAUNCH(true, false);
+    else DSS_LAUNCH(false, false);
+#undef DSS_LAUNCH
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }
