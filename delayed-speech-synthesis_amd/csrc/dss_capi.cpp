@@ -725,6 +725,11 @@ struct dss_hga {
     int device;
     DssHgaDev d;
     int first_frame = 1;
+    // optional fused front end
+    int c_raw = 0, n_grids = 0;
+    int *d_src_col = nullptr, *d_grid_of = nullptr, *d_comp_cols = nullptr, *d_comp_off = nullptr;
+    double *d_pre = nullptr, *d_raw = nullptr;
+    size_t pre_cap = 0, raw_cap = 0;
     double *d_zi0[2] = {nullptr, nullptr};
     double *d_in = nullptr, *d_out = nullptr;
     size_t in_cap = 0, out_cap = 0;
@@ -781,7 +786,8 @@ extern "C" void dss_hga_destroy(dss_hga *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    void *ptrs[] = {h->d.zi, h->d.rows, h->d_zi0[0], h->d_zi0[1], h->d_in, h->d_out};
+    void *ptrs[] = {h->d.zi, h->d.rows, h->d_zi0[0], h->d_zi0[1], h->d_in, h->d_out, h->d_src_col, h->d_grid_of,
+                    h->d_comp_cols, h->d_comp_off, h->d_pre, h->d_raw};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
 }
@@ -842,6 +848,74 @@ extern "C" int dss_hga_extract(dss_hga *h, const double *data, int n, double *ou
     if (out_n > h->out_cap) { if (h->d_out) hipFree(h->d_out); DSS_HIP_CHECK(hipMalloc((void **)&h->d_out, out_n * sizeof(double))); h->out_cap = out_n; }
     DSS_HIP_CHECK(hipMemcpy(h->d_in, data, in_n * sizeof(double), hipMemcpyHostToDevice));
     const int W = dss_hga_extract_dev(h, h->d_in, n, h->d_out, 0, nullptr);
+    if (W < 0) return W;
+    if (W == 0) { DSS_HIP_CHECK(hipDeviceSynchronize()); return 0; }
+    const size_t cnt = (size_t)h->d.S * W * h->d.C;
+    DSS_HIP_CHECK(hipMemcpy(out, h->d_out, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < cnt; ++k) out[k] = log(out[k]);                 // pyx:46, host libm (DESIGN.md "HGA log")
+    return W;
+}
+
+
+extern "C" int dss_hga_set_frontend(dss_hga *h, int c_raw, const int *src_col, const int *grid_of, int n_grids,
+                                    const int *comp_cols, const int *comp_off)
+{
+    if (!h || c_raw <= 0 || !src_col || !grid_of || n_grids < 0 || n_grids > 4 || (n_grids && (!comp_cols || !comp_off))) {
+        dss_set_error("bad front-end description (at most 4 grids)");
+        return DSS_EINVAL;
+    }
+    const int C = h->d.C;
+    for (int c = 0; c < C; ++c)
+        if (src_col[c] < 0 || src_col[c] >= c_raw || grid_of[c] >= n_grids) { dss_set_error("front-end column %d out of range", c); return DSS_EINVAL; }
+    const int n_comp = n_grids ? comp_off[n_grids] : 0;
+    for (int g = 0; g < n_grids; ++g)
+        if (comp_off[g + 1] <= comp_off[g]) { dss_set_error("grid %d has no reference channels", g); return DSS_EINVAL; }
+    for (int k = 0; k < n_comp; ++k)
+        if (comp_cols[k] < 0 || comp_cols[k] >= c_raw) { dss_set_error("reference column out of range"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    int rc = dev_upload<int>(src_col, C, &h->d_src_col);
+    rc |= dev_upload<int>(grid_of, C, &h->d_grid_of);
+    static const int zero2[2] = {0, 0};
+    rc |= dev_upload<int>(n_comp ? comp_cols : zero2, n_comp ? n_comp : 1, &h->d_comp_cols);
+    rc |= dev_upload<int>(n_grids ? comp_off : zero2, n_grids + 1, &h->d_comp_off);
+    if (rc) return DSS_ENOMEM;
+    h->c_raw = c_raw; h->n_grids = n_grids;
+    return DSS_OK;
+}
+
+extern "C" int dss_hga_extract_raw_dev(dss_hga *h, const double *d_raw, int n, double *d_out, int apply_log, void *hip_stream)
+{
+    if (!h || !h->c_raw) { dss_set_error("no front end configured (dss_hga_set_frontend)"); return DSS_EINVAL; }
+    if (!d_raw || !d_out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    const size_t need = (size_t)h->d.S * n * h->d.C;
+    if (need > h->pre_cap) {
+        if (h->d_pre) hipFree(h->d_pre);
+        DSS_HIP_CHECK(hipMalloc((void **)&h->d_pre, need * sizeof(double)));
+        h->pre_cap = need;
+    }
+    int rc = dss_launch_hga_frontend(d_raw, h->d_pre, h->d.S, n, h->c_raw, h->d.C, h->d_src_col, h->d_grid_of, h->n_grids,
+                                     h->d_comp_cols, h->d_comp_off, (hipStream_t)hip_stream);
+    if (rc) return rc;
+    return dss_hga_extract_dev(h, h->d_pre, n, d_out, apply_log, hip_stream);
+}
+
+extern "C" int dss_hga_extract_raw(dss_hga *h, const double *raw, int n, double *out)
+{
+    if (!h || !h->c_raw) { dss_set_error("no front end configured (dss_hga_set_frontend)"); return DSS_EINVAL; }
+    if (!raw || !out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    const size_t in_n = (size_t)h->d.S * n * h->c_raw;
+    if (in_n > h->raw_cap) {
+        if (h->d_raw) hipFree(h->d_raw);
+        DSS_HIP_CHECK(hipMalloc((void **)&h->d_raw, in_n * sizeof(double)));
+        h->raw_cap = in_n;
+    }
+    const int Wmax = dss_hga_frames_for(h, n);
+    const size_t out_n = (size_t)h->d.S * (Wmax > 0 ? Wmax : 1) * h->d.C;
+    if (out_n > h->out_cap) { if (h->d_out) hipFree(h->d_out); DSS_HIP_CHECK(hipMalloc((void **)&h->d_out, out_n * sizeof(double))); h->out_cap = out_n; }
+    DSS_HIP_CHECK(hipMemcpy(h->d_raw, raw, in_n * sizeof(double), hipMemcpyHostToDevice));
+    const int W = dss_hga_extract_raw_dev(h, h->d_raw, n, h->d_out, 0, nullptr);
     if (W < 0) return W;
     if (W == 0) { DSS_HIP_CHECK(hipDeviceSynchronize()); return 0; }
     const size_t cnt = (size_t)h->d.S * W * h->d.C;

@@ -174,3 +174,40 @@ int dss_launch_log_power(const double *d_data, int T, int C, int sr, float wl, f
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }
+
+
+// Fused front end: column reorder + per-grid common average reference + channel selection, one lane per
+// (stream, sample).  The grid mean is a sequential sum in the reference's column order (numpy reduces the
+// Fortran-ordered fancy-index view column by column), then one division: bit-identical to the numpy chain.
+__global__ void __launch_bounds__(64)
+hga_frontend_kernel(const double *__restrict__ raw, double *__restrict__ pre, int total, int c_raw, int C,
+                    const int *__restrict__ src_col, const int *__restrict__ grid_of, int n_grids,
+                    const int *__restrict__ comp_cols, const int *__restrict__ comp_off)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const double *row = raw + (size_t)gid * c_raw;
+    double mean[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < n_grids && g < 4; ++g) {
+        double sum = 0.0;
+        const int a = comp_off[g], b2 = comp_off[g + 1];
+        for (int k = a; k < b2; ++k) sum += row[comp_cols[k]];
+        mean[g] = sum / (double)(b2 - a);
+    }
+    double *o = pre + (size_t)gid * C;
+    for (int c = 0; c < C; ++c) {
+        const int g = grid_of[c];
+        const double v = row[src_col[c]];
+        o[c] = g >= 0 ? v - mean[g] : v;
+    }
+}
+
+int dss_launch_hga_frontend(const double *d_raw, double *d_pre, int S, int n, int c_raw, int C, const int *src_col,
+                            const int *grid_of, int n_grids, const int *comp_cols, const int *comp_off, hipStream_t st)
+{
+    const int total = S * n;
+    hipLaunchKernelGGL(hga_frontend_kernel, dim3((total + 63) / 64), dim3(64), 0, st, d_raw, d_pre, total, c_raw, C, src_col,
+                       grid_of, n_grids, comp_cols, comp_off);
+    DSS_HIP_CHECK(hipGetLastError());
+    return DSS_OK;
+}

@@ -52,6 +52,9 @@ def _declare(L):
         "dss_hga_frames_for": (i, [vp, i]),
         "dss_hga_extract": (i, [vp, vp, i, vp]),
         "dss_hga_extract_dev": (i, [vp, vp, i, vp, i, vp]),
+        "dss_hga_set_frontend": (i, [vp, i, vp, vp, i, vp, vp]),
+        "dss_hga_extract_raw": (i, [vp, vp, i, vp]),
+        "dss_hga_extract_raw_dev": (i, [vp, vp, i, vp, i, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

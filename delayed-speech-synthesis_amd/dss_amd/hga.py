@@ -83,6 +83,56 @@ class HgaExtractorGPU:
         assert got == W
         return out[:, :W].reshape(self.S, W, self.C) if W else np.empty((self.S, 0, self.C))
 
+    # ---- fused front end (column reorder + per-grid CAR + channel selection) -------------------------------
+    def set_frontend(self, c_raw: int, src_col, grid_of, comp_lists):
+        """output channel c = raw[src_col[c]] - mean(raw[comp_lists[grid_of[c]]]) (sequential mean, numpy order)."""
+        src = np.ascontiguousarray(src_col, dtype=np.int32)
+        gof = np.ascontiguousarray(grid_of, dtype=np.int32)
+        assert src.shape == (self.C,) and gof.shape == (self.C,)
+        comp = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.int32) for c in comp_lists])
+                                    if len(comp_lists) else np.zeros(1, np.int32), dtype=np.int32)
+        off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([len(c) for c in comp_lists])]), dtype=np.int32)
+        _lib.check(self._L.dss_hga_set_frontend(self._h, int(c_raw), src.ctypes.data, gof.ctypes.data, len(comp_lists),
+                                                comp.ctypes.data, off.ctypes.data))
+        self.c_raw = int(c_raw)
+
+    def set_frontend_from_transforms(self, c_raw: int, select_all, car, select_sub) -> None:
+        """Build the fused front end from the reference's three pre-transform objects (decode_online.py:65-85):
+        SelectElectrodesFromBothGrids -> CommonAverageReferencing -> SelectElectrodesOverSpeechAreas."""
+        sel1 = np.asarray(select_all.grid_mapping, dtype=np.int64)          # column of raw for each mid channel
+        sel2 = np.asarray(select_sub.speech_grid_mapping, dtype=np.int64)   # mid channel of each output channel
+        grid_of_mid = np.full(len(sel1), -1, dtype=np.int64)
+        comp_lists = []
+        for g, (used, applied) in enumerate(zip(car.selection_masks_computation, car.selection_masks_application)):
+            grid_of_mid[np.nonzero(applied)[0]] = g
+            comp_lists.append(sel1[np.nonzero(used)[0]])                    # ascending mid index = numpy's order
+        self.set_frontend(c_raw, sel1[sel2], grid_of_mid[sel2], comp_lists)
+
+    def extract_raw(self, raw: np.ndarray) -> np.ndarray:
+        """(S, n, c_raw) raw amplifier packets -> (S, W, C) frames, front end + filters + log power on the GPU."""
+        d = np.ascontiguousarray(raw, dtype=np.float64)
+        if d.ndim == 2:
+            d = d[None]
+        if d.shape[0] != self.S or d.shape[2] != self.c_raw:
+            raise ValueError(f"expected ({self.S}, n, {self.c_raw}), got {d.shape}")
+        n = d.shape[1]
+        W = self.frames_for(n)
+        out = np.empty((self.S, max(W, 1), self.C), dtype=np.float64)
+        got = _lib.check(self._L.dss_hga_extract_raw(self._h, d.ctypes.data, n, out.ctypes.data))
+        assert got == W
+        return out[:, :W].reshape(self.S, W, self.C) if W else np.empty((self.S, 0, self.C))
+
+    def extract_raw_torch(self, raw, apply_log: bool = True, stream=None):
+        import torch
+        assert raw.is_cuda and raw.dtype == torch.float64 and raw.is_contiguous() and raw.shape[2] == self.c_raw
+        n = raw.shape[1]
+        W = self.frames_for(n)
+        out = torch.empty((self.S, W, self.C), dtype=torch.float64, device=raw.device)
+        s = torch.cuda.current_stream(raw.device).cuda_stream if stream is None else stream
+        got = _lib.check(self._L.dss_hga_extract_raw_dev(self._h, raw.data_ptr(), n, out.data_ptr(), int(apply_log), s))
+        assert got == W
+        return out
+
     def extract_torch(self, data, apply_log: bool = True, out=None, stream=None):
         """Device-resident: (S, n, C) float64 CUDA tensor -> (S, W, C) float64 CUDA tensor."""
         import torch

@@ -125,12 +125,24 @@ class HighGammaExtractor:
         self.hg_filter, self.fh_filter, zi_hg, zi_fh = design_filters(fs, l_freq, h_freq, order=8)
         self._gpu = HgaExtractorGPU(1, nb_electrodes, fs=fs, window_length=window_length, window_shift=window_shift,
                                     filters=(self.hg_filter, self.fh_filter, zi_hg, zi_fh))
+        # decode_online.py's pre-transform chain (reorder -> CAR -> select) is fused into the GPU front end
+        self._fused_pre = None
+        if pre_transforms is not None and len(pre_transforms) == 3 and hasattr(pre_transforms[0], "grid_mapping") \
+                and hasattr(pre_transforms[1], "selection_masks_computation") \
+                and hasattr(pre_transforms[2], "speech_grid_mapping") \
+                and len(pre_transforms[2].speech_grid_mapping) == nb_electrodes:
+            self._fused_pre = tuple(pre_transforms)
 
     @staticmethod
     def _compose_functions(*functions):
         return reduce(lambda f, g: lambda x: g(f(x)), functions, lambda x: x)
 
     def extract_features(self, data: np.ndarray):
+        if self._fused_pre is not None:
+            if getattr(self._gpu, "c_raw", None) != data.shape[1]:
+                self._gpu.set_frontend_from_transforms(data.shape[1], *self._fused_pre)
+            data = self._gpu.extract_raw(np.ascontiguousarray(data, dtype=np.float64))[0]
+            return self.post_transform(data) if self.post_transform is not None else data
         if self.pre_transform is not None:
             data = self.pre_transform(data)
         data = self._gpu.extract(np.ascontiguousarray(data, dtype=np.float64))[0]

@@ -132,6 +132,16 @@ int dss_hga_frames_for(const dss_hga *h, int n);
 /* extract_features (units.py:145-161): data host (n_streams, n, C) float64 -> out host (n_streams, W, C).
  * Returns W (>= 0) or a negative error.  All streams advance by the same n. */
 int dss_hga_extract(dss_hga *h, const double *data, int n, double *out);
+/* Fused front end: the pre-transforms decode_online.py:65-97 puts in front of the filters --
+ * column reorder (local/common.py:31-32), per-grid common average referencing with excluded channels
+ * (common.py:338-345) and channel selection (common.py:54-55) -- collapse to: output channel c =
+ * raw[src_col[c]] - mean_g(c), where mean_g is the SEQUENTIAL sum (numpy reduces the fancy-indexed, Fortran-ordered
+ * view one column at a time) of raw[comp_cols[comp_off[g] .. comp_off[g+1])] divided by their count, g = grid_of[c]
+ * (-1: no referencing).  After this call dss_hga_extract_raw* take raw amplifier packets (n, c_raw). */
+int dss_hga_set_frontend(dss_hga *h, int c_raw, const int *src_col, const int *grid_of, int n_grids,
+                         const int *comp_cols, const int *comp_off);
+int dss_hga_extract_raw(dss_hga *h, const double *raw, int n, double *out);
+int dss_hga_extract_raw_dev(dss_hga *h, const double *d_raw, int n, double *d_out, int apply_log, void *hip_stream);
 /* Device-resident form: d_data / d_out device pointers; log applied on the device (OCML log, <= 1 ulp
  * from the host's) when apply_log != 0, else out = mean power + 0.01. */
 int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, int apply_log, void *hip_stream);

@@ -41,9 +41,16 @@ def test_extractor_with_pre_and_post_transforms(golden):
     post = ZScoreNormalization(np.full((1, 64), 3.0), np.full((1, 64), 2.0))
     ex = U.HighGammaExtractor(1000, 64, pre_transforms=[both, car, speech], post_transforms=[post])
     raw = synthetic_ecog(77, 200, 129)
+    assert ex._fused_pre is not None                       # reorder + CAR + select run in the GPU front-end kernel
     got = ex.extract_features(raw)
-    plain = U.HighGammaExtractor(1000, 64).extract_features(speech(car(both(raw))))
-    assert got.shape == (16, 64) and np.array_equal(got, (plain - 3.0) / 2.0)
+    plain = U.HighGammaExtractor(1000, 64).extract_features(speech(car(both(raw))))       # numpy transforms
+    assert got.shape == (16, 64) and np.array_equal(got, (plain - 3.0) / 2.0)            # bit-identical
+    # state carries across packets on the fused path too
+    more = ex.extract_features(synthetic_ecog(78, 40, 129))
+    assert more.shape == (4, 64) and np.isfinite(more).all()
+    # a transform chain that is not the reference's falls back to the host transforms
+    ex2 = U.HighGammaExtractor(1000, 64, pre_transforms=[both, speech])
+    assert ex2._fused_pre is None and ex2.extract_features(raw).shape == (16, 64)
 
 
 def test_vocoder_unit_segments_and_state_carry(oracle):
