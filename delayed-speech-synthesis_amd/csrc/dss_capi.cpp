@@ -319,7 +319,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         std::stable_sort(order_zr.begin(), order_zr.end(), [&](int a, int b2) {
             return std::max(cnt[a], cnt[G + a]) > std::max(cnt[b2], cnt[G + b2]);
         });
-        static const int rank_wave_h[6] = {0, 1, 4, 5, 2, 3};
+        static const int rank_wave_h[6] = {0, 1, 3, 2, 5, 4};
         static const int rank_wave_zr[6] = {3, 2, 5, 4, 1, 0};
         std::vector<int> unit_of(NA, 0), unit_h(NA, 0), wave_nh(8, 0), wave_hoff(8, 0), wave_nzr(8, 0), grp_h(G, 0), grp_zr(G, 0);
         int hfloats = 0;

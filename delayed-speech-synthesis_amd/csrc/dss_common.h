@@ -24,7 +24,7 @@
 // (or whose h-gate block image does not fit DSS_HBLK_BYTES of LDS) runs on the generic kernel instead.
 #define DSS_ZRC 12            // register slots per lane for the z-gate and for the r-gate 8x4 blocks
 #define DSS_HC 28             // max h-gate blocks per row group (LDS resident; column ids in 7 VGPRs)
-#define DSS_HBLK_BYTES 139264  // dynamic LDS left after the kernel's static 24 KB (160 KB per CU)
+#define DSS_HBLK_BYTES 137728  // dynamic LDS left after the kernel's static 24 KB (160 KB per CU)
 
 void dss_set_error(const char *fmt, ...);
 

@@ -44,7 +44,12 @@ struct SampleLds {
     float gb_wl[NB3 * GBL_STRIDE];        // GRU B input weights of the last GBHL inputs, row-major
     float tansig[208];
     float ulaw2lin[256];
-    float logit_table[256];
+    float spec_tab_pred[256];             // speculation over all 256 excitation values (see role A, B..C):
+    unsigned short spec_tab_idx[256];     //   next sample's prediction and its two mu-law indices (su | pu << 8)
+    float spec_ls[DSS_LPC_ORDER];         // inputs of the speculation, published by wave 7: signal history,
+    float spec_lpc[DSS_LPC_ORDER];        //   the LPC of the next sample's frame,
+    float spec_pred;                      //   and this sample's prediction
+    float pad1[3];
     float gb_acc[64];                     // GRU B partial sums handed from wave 6 to wave 7
     float ah[NA];                         // h-gate pre-activation: written by a unit's h lane, read by its z/r lane
     float state_b[NB];
@@ -181,6 +186,26 @@ struct SampleLds {
         acc += p1.y;                                                                             \
     }
 
+// wave 7: fold the sampled excitation into the signal history and emit the PCM sample (lpcnet_synthesize_tail_impl)
+#define DSS_S_UPDATE()                                                                           \
+    {                                                                                            \
+        float pcm = upd_pred + L.ulaw2lin[upd_exc];                                              \
+        if (TRACE && lane == 0) {                                                                \
+            const size_t o = ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + upd_i;              \
+            b.trace_exc[o] = (float)upd_exc;                                                     \
+            b.trace_pcm[o] = pcm;                                                                \
+        }                                                                                        \
+        _Pragma("unroll") for (int j = DSS_LPC_ORDER - 1; j > 0; --j) last_sig[j] = last_sig[j - 1]; \
+        last_sig[0] = pcm;                                                                       \
+        last_exc = upd_exc;                                                                      \
+        pcm += 0.85f * deemph;                                                                   \
+        deemph = pcm;                                                                            \
+        if (pcm < -32767) pcm = -32767;                                                          \
+        if (pcm > 32767) pcm = 32767;                                                            \
+        if (lane == 0) L.pcm[upd_i] = (short)(int)floor(.5 + (double)pcm);                       \
+        upd_pending = false;                                                                     \
+    }
+
 template <bool TRACE, bool STAMP, int Z>
 __global__ void __launch_bounds__(512)
 lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restrict__ pcm_out)
@@ -202,7 +227,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         L.gb_wl[row * GBL_STRIDE + j] = m.gb_w_lane[(size_t)(GBH6 + GBH7 + j) * 64 + row];
     }
     if (tid < 201) L.tansig[tid] = m.tansig[tid];
-    if (tid < 256) { L.ulaw2lin[tid] = m.ulaw2lin[tid]; L.logit_table[tid] = m.logit_table[tid]; }
+    if (tid < 256) L.ulaw2lin[tid] = m.ulaw2lin[tid];
     if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)utt * NA + tid];
     if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)utt * NB + tid];
     if (tid == 0) L.gb_flag = 0;
@@ -246,6 +271,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
         }
         const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
+        const int cand = tid & 127;                                  // waves 4, 5: excitation candidates cand, cand+128
+        const float u2l_a = L.ulaw2lin[cand], u2l_b = L.ulaw2lin[cand + 128];
         int cur = 0;
         float st = L.state_a[0][unit];
         unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
@@ -313,6 +340,27 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
                 DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
                 DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
+                if (wave >= 4) {
+                    // Speculation over all 256 possible excitation values of THIS sample (waves 4 and 5, two
+                    // candidates per lane): the next sample's LPC prediction and mu-law indices, so that once the
+                    // tree walk has picked the value, wave 7 only looks the result up instead of running two
+                    // ~40-step dependent chains.  Same expressions, same order as lpcnet_synthesize_tail_impl().
+                    const float sp = L.spec_pred;
+                    const float pcm_a = sp + u2l_a, pcm_b = sp + u2l_b;
+                    const float l0 = L.spec_lpc[0];
+                    float pa = 0, pb = 0;
+                    pa -= pcm_a * l0; pb -= pcm_b * l0;
+#pragma unroll
+                    for (int j = 1; j < DSS_LPC_ORDER; ++j) {
+                        const float t2 = L.spec_ls[j - 1] * L.spec_lpc[j];          // same product for every candidate
+                        pa -= t2; pb -= t2;
+                    }
+                    const int su_a = dss_lin2ulaw(pcm_a), su_b = dss_lin2ulaw(pcm_b);
+                    const int pu_a = dss_lin2ulaw(pa), pu_b = dss_lin2ulaw(pb);
+                    L.spec_tab_pred[cand] = pa; L.spec_tab_pred[cand + 128] = pb;
+                    L.spec_tab_idx[cand] = (unsigned short)(su_a | (pu_a << 8));
+                    L.spec_tab_idx[cand + 128] = (unsigned short)(su_b | (pu_b << 8));
+                }
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
@@ -398,6 +446,9 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long t_prev = 0;
         int cur = 0, seq = 0;
+        float pred = 0.f, upd_pred = 0.f;
+        int upd_exc = 0, upd_i = 0;
+        bool have_spec = false, next_exists = false, upd_pending = false;
         __syncthreads();                                             // matches role A's prologue barrier
         for (int f = 0; f < n_frames; ++f) {
             short *pcm_frame = pcm_out + ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE;
@@ -415,23 +466,40 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             for (int j = 0; j < DSS_LPC_ORDER; ++j) lpc[j] = fo[3 * NA + NB3 + j];
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
                 if (STAMP) t_prev = __builtin_readcyclecounter();
-                float pred = 0;
+                if (!have_spec) {        // first sample of the call: prediction and indices computed directly
+                    pred = 0;
 #pragma unroll
-                for (int j = 0; j < DSS_LPC_ORDER; ++j) pred -= last_sig[j] * lpc[j];
-                const int su = dss_lin2ulaw(last_sig[0]);
-                const int pu = dss_lin2ulaw(pred);
-                if (lane == 0) { L.idx[0] = su; L.idx[1] = pu; L.idx[2] = last_exc; }
+                    for (int j = 0; j < DSS_LPC_ORDER; ++j) pred -= last_sig[j] * lpc[j];
+                    const int su = dss_lin2ulaw(last_sig[0]);
+                    const int pu = dss_lin2ulaw(pred);
+                    if (lane == 0) { L.idx[0] = su; L.idx[1] = pu; L.idx[2] = last_exc; }
+                }
                 ++seq;
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[0] += t - t_prev; t_prev = t; }
                 __syncthreads();                                                        // barrier A
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[1] += t - t_prev; t_prev = t; }
+                if (upd_pending) { DSS_S_UPDATE() }                                     // previous sample's bookkeeping
                 {   // off the critical path: this sample's 8 thresholds and GRU B's recurrent half
                     const uint32_t r0 = dss_kiss99_rand(rng);
                     const uint32_t r1 = dss_kiss99_rand(rng);
                     if (lane < 8) {
                         const uint32_t r = lane < 4 ? r0 : r1;
-                        L.thr[lane] = L.logit_table[(r >> (8 * (lane & 3))) & 0xFF];
+                        L.thr[lane] = m.logit_table[(r >> (8 * (lane & 3))) & 0xFF];     // 1 KB table, L2/L1 resident
                     }
+                }
+                {   // inputs of the speculation the GRU A waves run between barriers B and C
+                    const bool last_of_frame = (i == DSS_FRAME_SIZE - 1);
+                    next_exists = !(last_of_frame && f == n_frames - 1);
+                    float lp = lpc[0];                       // lane j < 16 publishes element j
+#pragma unroll
+                    for (int j = 1; j < DSS_LPC_ORDER; ++j) lp = (lane == j) ? lpc[j] : lp;
+                    float ls = last_sig[0];
+#pragma unroll
+                    for (int j = 1; j < DSS_LPC_ORDER; ++j) ls = (lane == j) ? last_sig[j] : ls;
+                    if (last_of_frame && next_exists && lane < DSS_LPC_ORDER)
+                        lp = b.frame_out[((size_t)utt * n_frames + f + 1) * DSS_COND_STRIDE + 3 * NA + NB3 + lane];
+                    if (lane < DSS_LPC_ORDER) { L.spec_lpc[lane] = lp; L.spec_ls[lane] = ls; }
+                    if (lane == 0) L.spec_pred = pred;
                 }
                 float rec = gbb1;
 #pragma unroll
@@ -491,21 +559,17 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 { const int node = 64 | val; val = (val << 1) | (int)((m1 >> (node - 64)) & 1); }
                 { const int node = 128 | val; const unsigned long long mm = node < 192 ? m2 : m3; val = (val << 1) | (int)((mm >> (node & 63)) & 1); }
                 const int exc = val;
-                float pcm = pred + L.ulaw2lin[exc];
-                if (TRACE && lane == 0) {
-                    const size_t o = ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + i;
-                    b.trace_exc[o] = (float)exc;
-                    b.trace_pcm[o] = pcm;
-                }
-#pragma unroll
-                for (int j = DSS_LPC_ORDER - 1; j > 0; --j) last_sig[j] = last_sig[j - 1];
-                last_sig[0] = pcm;
-                last_exc = exc;
-                pcm += 0.85f * deemph;
-                deemph = pcm;
-                if (pcm < -32767) pcm = -32767;
-                if (pcm > 32767) pcm = 32767;
-                if (lane == 0) L.pcm[i] = (short)(int)floor(.5 + (double)pcm);
+                // the next sample's prediction and mu-law indices were precomputed for every possible exc
+                const unsigned sidx = L.spec_tab_idx[exc];
+                const float pred_next = L.spec_tab_pred[exc];
+                have_spec = next_exists;
+                if (have_spec && lane == 0) { L.idx[0] = (int)(sidx & 0xFF); L.idx[1] = (int)(sidx >> 8); L.idx[2] = exc; }
+                // Everything below only updates this wave's own state; except at the end of a frame (whose PCM is
+                // copied out right after the loop) it is deferred until after the next barrier A, off the path
+                // that the GRU A waves are waiting on.
+                upd_exc = exc; upd_pred = pred; upd_i = i; upd_pending = true;
+                pred = pred_next;
+                if (i == DSS_FRAME_SIZE - 1) { DSS_S_UPDATE() }
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[5] += t - t_prev; t_prev = t; }
             }
             // wave 7 owns L.pcm: LDS operations of one wave are ordered, no barrier needed
