@@ -24,6 +24,36 @@ __device__ __forceinline__ float dss_tanh_approx(const float *tab, float x)
     return sign * r;
 }
 
+// Two independent evaluations with both table reads issued before either is consumed (same arithmetic per
+// element as dss_tanh_approx; only the instruction interleaving differs).
+__device__ __forceinline__ void dss_tanh_approx2(const float *tab, float x1, float x2, float &o1, float &o2)
+{
+    float s1 = 1.f, s2 = 1.f;
+    if (x1 < 0) { x1 = -x1; s1 = -1.f; }
+    if (x2 < 0) { x2 = -x2; s2 = -1.f; }
+    int i1 = (int)floorf(.5f + 25 * x1);
+    int i2 = (int)floorf(.5f + 25 * x2);
+    i1 = i1 < 0 ? 0 : i1; i1 = i1 > 200 ? 200 : i1;
+    i2 = i2 < 0 ? 0 : i2; i2 = i2 > 200 ? 200 : i2;
+    const float y1 = tab[i1];
+    const float y2 = tab[i2];
+    x1 -= .04f * i1;
+    x2 -= .04f * i2;
+    const float d1 = 1 - y1 * y1, d2 = 1 - y2 * y2;
+    const float r1 = y1 + x1 * d1 * (1 - y1 * x1);
+    const float r2 = y2 + x2 * d2 * (1 - y2 * x2);
+    o1 = s1 * r1;
+    o2 = s2 * r2;
+}
+
+__device__ __forceinline__ void dss_sigmoid_approx2(const float *tab, float x1, float x2, float &o1, float &o2)
+{
+    float t1, t2;
+    dss_tanh_approx2(tab, .5f * x1, .5f * x2, t1, t2);
+    o1 = .5f + .5f * t1;
+    o2 = .5f + .5f * t2;
+}
+
 __device__ __forceinline__ float dss_sigmoid_approx(const float *tab, float x)
 {
     return .5f + .5f * dss_tanh_approx(tab, .5f * x);

@@ -328,8 +328,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                         }
                     }
                     if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
-                    const float z = dss_sigmoid_approx(L.tansig, az);
-                    const float r = dss_sigmoid_approx(L.tansig, ar);
+                    float z, r;
+                    dss_sigmoid_approx2(L.tansig, az, ar, z, r);
                     float h = ahv * r + gh;
                     h = dss_tanh_approx(L.tansig, h);
                     st = z * st + (1 - z) * h;
@@ -365,6 +365,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
                 if (tid < DSS_FC_OUT) {                                                 // sample_mdense, all nodes
+                    const float thr_lv = L.thr[level];                                  // issued first, used last
                     float s1 = fb0, s2 = fb1;
 #pragma unroll
                     for (int j4 = 0; j4 < NB / 4; ++j4) {
@@ -375,10 +376,12 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                         s1 += w0.z * bj.z; s2 += w1.z * bj.z;
                         s1 += w0.w * bj.w; s2 += w1.w * bj.w;
                     }
-                    s1 = ff0 * dss_tanh_approx(L.tansig, s1);
-                    s2 = ff1 * dss_tanh_approx(L.tansig, s2);
+                    float t1, t2;
+                    dss_tanh_approx2(L.tansig, s1, s2, t1, t2);
+                    s1 = ff0 * t1;
+                    s2 = ff1 * t2;
                     s1 += s2;
-                    const bool bit = L.thr[level] < s1;
+                    const bool bit = thr_lv < s1;
                     const unsigned long long mask = __ballot(bit);
                     if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
                 }
