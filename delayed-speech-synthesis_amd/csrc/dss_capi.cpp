@@ -470,6 +470,8 @@ struct dss_lpcnet_batch {
     int trace = 0, timing = 0;
     float *d_feat = nullptr;      // staging for the host-buffer entry point
     short *d_pcm = nullptr;
+    int *d_slots = nullptr;       // [max_utts] slot list of a ragged call
+    int *d_counts = nullptr;      // [max_utts] frame counts of a ragged call
     hipEvent_t ev[3];
     double ms_sum[2] = {0, 0};
     int ms_n = 0;
@@ -508,6 +510,8 @@ extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frame
     rc |= dev_alloc<int>(B, &d.fc0);
     rc |= dev_alloc<float>(B * F * 20, &b->d_feat);
     rc |= dev_alloc<short>(B * F * DSS_FRAME_SIZE, &b->d_pcm);
+    rc |= dev_alloc<int>(B, &b->d_slots);
+    rc |= dev_alloc<int>(B, &b->d_counts);
     for (int i = 0; i < 3; ++i) rc |= (hipEventCreate(&b->ev[i]) != hipSuccess);
     if (rc) { dss_set_error("device allocation failed for batch %d x %d", max_utts, max_frames); delete b; return nullptr; }
     if (dss_launch_lpcnet_reset(*m, d, -1, 0) || hipDeviceSynchronize() != hipSuccess) { delete b; return nullptr; }
@@ -521,7 +525,7 @@ extern "C" void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b)
     DssBatchDev &d = b->d;
     void *ptrs[] = {d.gru_a_state, d.gru_b_state, d.last_sig, d.last_exc, d.deemph, d.rng, d.frame_count, d.conv1_mem,
                     d.conv2_mem, d.old_lpc, d.in_buf, d.c1_buf, d.c2_buf, d.d1_buf, d.cond_buf, d.lpc_buf, d.frame_out,
-                    d.fc0, d.trace_exc, d.trace_pcm, b->d_feat, b->d_pcm};
+                    d.fc0, d.trace_exc, d.trace_pcm, b->d_feat, b->d_pcm, b->d_slots, b->d_counts};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 3; ++i) hipEventDestroy(b->ev[i]);
     delete b;
@@ -574,17 +578,21 @@ extern "C" double dss_lpcnet_batch_kernel_ms(dss_lpcnet_batch *b, int which)
     return v;
 }
 
-extern "C" int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float *d_features, int n_utts, int n_frames,
-                                               int feat_stride, short *d_pcm, void *hip_stream)
+static int check_batch_shape(dss_lpcnet_batch *b, int n_utts, int n_frames, int feat_stride)
 {
-    if (!b || !d_features || !d_pcm) { dss_set_error("null argument"); return DSS_EINVAL; }
     if (n_utts <= 0 || n_utts > b->d.max_utts || n_frames <= 0 || n_frames > b->d.max_frames || feat_stride < DSS_NB_FEATURES) {
         dss_set_error("shape out of range: %d utts (max %d), %d frames (max %d), stride %d", n_utts, b->d.max_utts, n_frames,
                       b->d.max_frames, feat_stride);
         return DSS_EINVAL;
     }
-    DSS_HIP_CHECK(hipSetDevice(b->device));
-    hipStream_t s = (hipStream_t)hip_stream;
+    return DSS_OK;
+}
+
+// frame-rate network, then the persistent sample-rate kernel, on stream s; b->d.slot_of / count_of select the
+// uniform (NULL) or the ragged form
+static int run_batch(dss_lpcnet_batch *b, const float *d_features, int n_utts, int n_frames, int feat_stride, short *d_pcm,
+                     hipStream_t s)
+{
     if (b->timing) DSS_HIP_CHECK(hipEventRecord(b->ev[0], s));
     int rc = dss_launch_frame_network(*b->model, b->d, d_features, n_utts, n_frames, feat_stride, s);
     if (rc) return rc;
@@ -603,15 +611,76 @@ extern "C" int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float 
     return DSS_OK;
 }
 
+extern "C" int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float *d_features, int n_utts, int n_frames,
+                                               int feat_stride, short *d_pcm, void *hip_stream)
+{
+    if (!b || !d_features || !d_pcm) { dss_set_error("null argument"); return DSS_EINVAL; }
+    int rc = check_batch_shape(b, n_utts, n_frames, feat_stride);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    b->d.slot_of = nullptr; b->d.count_of = nullptr;
+    return run_batch(b, d_features, n_utts, n_frames, feat_stride, d_pcm, (hipStream_t)hip_stream);
+}
+
+// Validate and upload the slot list / frame counts of a ragged call (either may be NULL).
+static int stage_ragged(dss_lpcnet_batch *b, const int *slots, const int *counts, int n_utts, int n_frames, hipStream_t s)
+{
+    b->d.slot_of = nullptr; b->d.count_of = nullptr;
+    if (slots) {
+        std::string seen((size_t)b->d.max_utts, 0);
+        for (int i = 0; i < n_utts; ++i) {
+            if (slots[i] < 0 || slots[i] >= b->d.max_utts) { dss_set_error("row %d: slot %d out of range (max %d)", i, slots[i], b->d.max_utts); return DSS_EINVAL; }
+            if (seen[slots[i]]) { dss_set_error("row %d: slot %d appears twice in one call (a decoder is sequential)", i, slots[i]); return DSS_EINVAL; }
+            seen[slots[i]] = 1;
+        }
+        DSS_HIP_CHECK(hipMemcpyAsync(b->d_slots, slots, sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
+        b->d.slot_of = b->d_slots;
+    }
+    if (counts) {
+        for (int i = 0; i < n_utts; ++i)
+            if (counts[i] < 0 || counts[i] > n_frames) { dss_set_error("row %d: %d frames outside [0, %d]", i, counts[i], n_frames); return DSS_EINVAL; }
+        DSS_HIP_CHECK(hipMemcpyAsync(b->d_counts, counts, sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
+        b->d.count_of = b->d_counts;
+    }
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_batch_synthesize_ragged_dev(dss_lpcnet_batch *b, const float *d_features, const int *slots,
+                                                      const int *counts, int n_utts, int n_frames, int feat_stride,
+                                                      short *d_pcm, void *hip_stream)
+{
+    if (!b || !d_features || !d_pcm) { dss_set_error("null argument"); return DSS_EINVAL; }
+    int rc = check_batch_shape(b, n_utts, n_frames, feat_stride);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    rc = stage_ragged(b, slots, counts, n_utts, n_frames, s);
+    if (rc) return rc;
+    return run_batch(b, d_features, n_utts, n_frames, feat_stride, d_pcm, s);
+}
+
+extern "C" int dss_lpcnet_batch_synthesize_ragged(dss_lpcnet_batch *b, const float *features, const int *slots,
+                                                  const int *counts, int n_utts, int n_frames, int feat_stride, short *pcm)
+{
+    if (!b || !features || !pcm) { dss_set_error("null argument"); return DSS_EINVAL; }
+    int rc = check_batch_shape(b, n_utts, n_frames, feat_stride);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    rc = stage_ragged(b, slots, counts, n_utts, n_frames, nullptr);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipMemcpy2D(b->d_feat, DSS_NB_FEATURES * sizeof(float), features, (size_t)feat_stride * sizeof(float),
+                              DSS_NB_FEATURES * sizeof(float), (size_t)n_utts * n_frames, hipMemcpyHostToDevice));
+    rc = run_batch(b, b->d_feat, n_utts, n_frames, DSS_NB_FEATURES, b->d_pcm, nullptr);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipMemcpy(pcm, b->d_pcm, (size_t)n_utts * n_frames * DSS_FRAME_SIZE * sizeof(short), hipMemcpyDeviceToHost));
+    return DSS_OK;
+}
+
 extern "C" int dss_lpcnet_batch_synthesize(dss_lpcnet_batch *b, const float *features, int n_utts, int n_frames,
                                            int feat_stride, short *pcm)
 {
     if (!b || !features || !pcm) { dss_set_error("null argument"); return DSS_EINVAL; }
-    if (n_utts <= 0 || n_utts > b->d.max_utts || n_frames <= 0 || n_frames > b->d.max_frames || feat_stride < DSS_NB_FEATURES) {
-        dss_set_error("shape out of range: %d utts (max %d), %d frames (max %d), stride %d", n_utts, b->d.max_utts, n_frames,
-                      b->d.max_frames, feat_stride);
-        return DSS_EINVAL;
-    }
+    if (check_batch_shape(b, n_utts, n_frames, feat_stride)) return DSS_EINVAL;
     DSS_HIP_CHECK(hipSetDevice(b->device));
     // pack the first 20 floats of every row (feature files carry 36, LPCNet.pyx:97,115)
     DSS_HIP_CHECK(hipMemcpy2D(b->d_feat, DSS_NB_FEATURES * sizeof(float), features, (size_t)feat_stride * sizeof(float),

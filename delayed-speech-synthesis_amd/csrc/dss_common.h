@@ -105,6 +105,9 @@ struct DssBatchDev {
     float *lpc_buf;       // [B][F+2][16]
     float *frame_out;     // [B][F][DSS_COND_STRIDE]  gru_a_condition | gru_b_condition | lpc
     int *fc0;             // [B] frame_count at the start of the call
+    // ragged / slot-indexed calls (NULL = row i continues slot i, every row has n_frames frames)
+    const int *slot_of;   // [n] decoder slot continued by row i of the call
+    const int *count_of;  // [n] frames of row i (<= n_frames of the call; 0 leaves the slot untouched)
     // trace (optional)
     float *trace_exc, *trace_pcm;   // [B][F*160]
 };

@@ -25,10 +25,11 @@ frame_prepare_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ fea
     const int utt = blockIdx.y, row = blockIdx.x, tid = threadIdx.x;      // row in [0, F+2)
     float *in = b.in_buf + ((size_t)utt * (n_frames + 2) + row) * FIN;
     if (row < 2) {
-        if (tid < FIN) in[tid] = b.conv1_mem[((size_t)utt * 2 + row) * FIN + tid];
-        b.c1_buf[((size_t)utt * (n_frames + 2) + row) * 128 + tid] = b.conv2_mem[((size_t)utt * 2 + row) * 128 + tid];
-        if (tid < 16) b.lpc_buf[((size_t)utt * (n_frames + 2) + row) * 16 + tid] = b.old_lpc[((size_t)utt * 2 + row) * 16 + tid];
-        if (row == 0 && tid == 0) b.fc0[utt] = b.frame_count[utt];
+        const int slot = b.slot_of ? b.slot_of[utt] : utt;                // carried state of this row's decoder
+        if (tid < FIN) in[tid] = b.conv1_mem[((size_t)slot * 2 + row) * FIN + tid];
+        b.c1_buf[((size_t)utt * (n_frames + 2) + row) * 128 + tid] = b.conv2_mem[((size_t)slot * 2 + row) * 128 + tid];
+        if (tid < 16) b.lpc_buf[((size_t)utt * (n_frames + 2) + row) * 16 + tid] = b.old_lpc[((size_t)slot * 2 + row) * 16 + tid];
+        if (row == 0 && tid == 0) b.fc0[utt] = b.frame_count[slot];
         return;
     }
     const float *f = feat + ((size_t)utt * n_frames + (row - 2)) * feat_stride;
@@ -182,16 +183,19 @@ frame_finish_kernel(DssBatchDev b, int n_frames)
                 b.lpc_buf[((size_t)utt * (n_frames + 2) + t) * 16 + tid];       // lpc of frame t-2 (old_lpc chain)
         return;
     }
-    // t == n_frames: one block per utterance updates the carried state
+    // t == n_frames: one block per utterance updates the carried state from the last two rows it really consumed
+    // (rows beyond a ragged utterance's own count are computed but never looked at)
+    const int slot = b.slot_of ? b.slot_of[utt] : utt;
+    const int nf = b.count_of ? min(b.count_of[utt], n_frames) : n_frames;
     for (int row = 0; row < 2; ++row) {
-        const size_t src = (size_t)utt * (n_frames + 2) + n_frames + row;
-        if (tid < FIN) b.conv1_mem[((size_t)utt * 2 + row) * FIN + tid] = b.in_buf[src * FIN + tid];
-        b.conv2_mem[((size_t)utt * 2 + row) * 128 + tid] = b.c1_buf[src * 128 + tid];
-        if (tid < 16) b.old_lpc[((size_t)utt * 2 + row) * 16 + tid] = b.lpc_buf[src * 16 + tid];
+        const size_t src = (size_t)utt * (n_frames + 2) + nf + row;
+        if (tid < FIN) b.conv1_mem[((size_t)slot * 2 + row) * FIN + tid] = b.in_buf[src * FIN + tid];
+        b.conv2_mem[((size_t)slot * 2 + row) * 128 + tid] = b.c1_buf[src * 128 + tid];
+        if (tid < 16) b.old_lpc[((size_t)slot * 2 + row) * 16 + tid] = b.lpc_buf[src * 16 + tid];
     }
     if (tid == 0) {
-        int fc = b.fc0[utt] + n_frames;
-        b.frame_count[utt] = fc > 1000 ? 1000 : fc;
+        int fc = b.fc0[utt] + nf;
+        b.frame_count[slot] = fc > 1000 ? 1000 : fc;
     }
 }
 

@@ -206,14 +206,20 @@ struct SampleLds {
         upd_pending = false;                                                                     \
     }
 
-template <bool TRACE, bool STAMP, int Z>
+// RAGGED: rows name their decoder slot and frame count (b.slot_of / b.count_of).  A separate instantiation, so the
+// uniform form keeps its register allocation (the two extra live scalars cost 1.3 % there); the trace build always
+// honours the lists.
+template <bool TRACE, bool STAMP, int Z, bool RAGGED>
 __global__ void __launch_bounds__(512)
 lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restrict__ pcm_out)
 {
     __shared__ __attribute__((aligned(16))) SampleLds L;
     extern __shared__ __attribute__((aligned(16))) float hblk_lds[];       // h-gate block records (size per model)
     static_assert(sizeof(SampleLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
-    const int utt = blockIdx.x;
+    const int utt = blockIdx.x;                                            // row of this call (scratch, features, PCM)
+    constexpr bool RG = RAGGED || TRACE;
+    const int slot = (RG && b.slot_of) ? b.slot_of[utt] : utt;                     // decoder state it continues
+    const int nf = (RG && b.count_of) ? min(b.count_of[utt], n_frames) : n_frames; // its own frame count
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -228,8 +234,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     }
     if (tid < 201) L.tansig[tid] = m.tansig[tid];
     if (tid < 256) L.ulaw2lin[tid] = m.ulaw2lin[tid];
-    if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)utt * NA + tid];
-    if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)utt * NB + tid];
+    if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)slot * NA + tid];
+    if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)slot * NB + tid];
     if (tid == 0) L.gb_flag = 0;
     const int fc0 = b.fc0[utt];
     __syncthreads();
@@ -281,7 +287,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         DSS_ZR_PRODUCTS(L.state_a[0])
         __syncthreads();                                             // L.ah of every unit visible to its z/r lane
 
-        for (int f = 0; f < n_frames; ++f) {
+        for (int f = 0; f < nf; ++f) {
             if (fc0 + f < DSS_FEATURES_DELAY) continue;              // silent frame: decoder state untouched
             const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;     // wave-uniform base
             const float cz = fo[(unsigned)unit], cr = fo[(unsigned)(NA + unit)], ch = fo[(unsigned)(2 * NA + unit)];
@@ -393,7 +399,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         __syncthreads();                                                                // final barrier
         if (STAMP && lane == 0 && b.trace_exc)
             for (int k = 0; k < 8; ++k) b.trace_exc[((size_t)utt * 6 + wave) * 8 + k] = (float)sa[k];
-        b.gru_a_state[(size_t)utt * NA + unit] = st;
+        b.gru_a_state[(size_t)slot * NA + unit] = st;
     } else if (wave == 6) {
         // =====================================================================================================
         // role B1: GRU B over inputs 0..207, lane = row (0..15 z, 16..31 r, 32..47 h)
@@ -409,7 +415,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         const float gbb0 = m.gru_b_bias[row];
         int cur = 0, seq = 0;
         __syncthreads();                                             // matches role A's prologue barrier
-        for (int f = 0; f < n_frames; ++f) {
+        for (int f = 0; f < nf; ++f) {
             if (fc0 + f < DSS_FEATURES_DELAY) continue;
             const float gbc = b.frame_out[((size_t)utt * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row];
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
@@ -442,10 +448,10 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         const float gbb1 = m.gru_b_bias[NB3 + row];
         float last_sig[DSS_LPC_ORDER], lpc[DSS_LPC_ORDER];
 #pragma unroll
-        for (int j = 0; j < DSS_LPC_ORDER; ++j) { last_sig[j] = b.last_sig[(size_t)utt * DSS_LPC_ORDER + j]; lpc[j] = 0.f; }
-        float deemph = b.deemph[utt];
-        int last_exc = b.last_exc[utt];
-        DssKiss99 rng = {b.rng[utt * 4 + 0], b.rng[utt * 4 + 1], b.rng[utt * 4 + 2], b.rng[utt * 4 + 3]};
+        for (int j = 0; j < DSS_LPC_ORDER; ++j) { last_sig[j] = b.last_sig[(size_t)slot * DSS_LPC_ORDER + j]; lpc[j] = 0.f; }
+        float deemph = b.deemph[slot];
+        int last_exc = b.last_exc[slot];
+        DssKiss99 rng = {b.rng[slot * 4 + 0], b.rng[slot * 4 + 1], b.rng[slot * 4 + 2], b.rng[slot * 4 + 3]};
         unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long t_prev = 0;
         int cur = 0, seq = 0;
@@ -453,7 +459,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         int upd_exc = 0, upd_i = 0;
         bool have_spec = false, next_exists = false, upd_pending = false;
         __syncthreads();                                             // matches role A's prologue barrier
-        for (int f = 0; f < n_frames; ++f) {
+        for (int f = 0; f < nf; ++f) {
             short *pcm_frame = pcm_out + ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE;
             if (fc0 + f < DSS_FEATURES_DELAY) {             // lpcnet.c: frame_count <= FEATURES_DELAY -> silence
                 for (int k = lane; k < DSS_FRAME_SIZE / 2; k += 64) reinterpret_cast<int *>(pcm_frame)[k] = 0;
@@ -492,7 +498,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 }
                 {   // inputs of the speculation the GRU A waves run between barriers B and C
                     const bool last_of_frame = (i == DSS_FRAME_SIZE - 1);
-                    next_exists = !(last_of_frame && f == n_frames - 1);
+                    next_exists = !(last_of_frame && f == nf - 1);
                     float lp = lpc[0];                       // lane j < 16 publishes element j
 #pragma unroll
                     for (int j = 1; j < DSS_LPC_ORDER; ++j) lp = (lane == j) ? lpc[j] : lp;
@@ -582,13 +588,13 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         __syncthreads();                                                                // final barrier
         if (STAMP && lane == 0 && b.trace_pcm)          // diagnostic build only
             for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)utt * 6 + k] = (float)stamp_acc[k];
-        if (lane < NB) b.gru_b_state[(size_t)utt * NB + lane] = L.state_b[lane];
+        if (lane < NB) b.gru_b_state[(size_t)slot * NB + lane] = L.state_b[lane];
         if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < DSS_LPC_ORDER; ++j) b.last_sig[(size_t)utt * DSS_LPC_ORDER + j] = last_sig[j];
-            b.deemph[utt] = deemph;
-            b.last_exc[utt] = last_exc;
-            b.rng[utt * 4 + 0] = rng.z; b.rng[utt * 4 + 1] = rng.w; b.rng[utt * 4 + 2] = rng.jsr; b.rng[utt * 4 + 3] = rng.jcong;
+            for (int j = 0; j < DSS_LPC_ORDER; ++j) b.last_sig[(size_t)slot * DSS_LPC_ORDER + j] = last_sig[j];
+            b.deemph[slot] = deemph;
+            b.last_exc[slot] = last_exc;
+            b.rng[slot * 4 + 0] = rng.z; b.rng[slot * 4 + 1] = rng.w; b.rng[slot * 4 + 2] = rng.jsr; b.rng[slot * 4 + 3] = rng.jcong;
         }
     }
 }
@@ -603,20 +609,24 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
     static bool attr_set = false;
     if (!attr_set) {      // one workgroup uses (almost) the whole 160 KB of the CU
 #define DSS_SET_ATTR(K) DSS_HIP_CHECK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES))
-        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10>)); DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12>));
-        DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 10>));  DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 12>));
-        DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 10>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 12>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, false>)); DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, false>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, true>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, true>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 10, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 12, false>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 10, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 12, false>));
 #undef DSS_SET_ATTR
         attr_set = true;
     }
-#define DSS_LAUNCH(T, S2)                                                                                              \
+    const bool ragged = b.slot_of || b.count_of;
+    if (ragged && trace == 2) { dss_set_error("phase stamps are taken on uniform calls only"); return DSS_EINVAL; }
+#define DSS_LAUNCH(T, S2, R)                                                                                           \
     do {                                                                                                               \
-        if (z10) hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 10>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm); \
-        else hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 12>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);     \
+        if (z10) hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 10, R>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm); \
+        else hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 12, R>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);     \
     } while (0)
-    if (trace == 2) DSS_LAUNCH(false, true);        // diagnostic: phase stamps (never used for timing claims)
-    else if (trace) DSS_LAUNCH(true, false);
-    else DSS_LAUNCH(false, false);
+    if (trace == 2) DSS_LAUNCH(false, true, false);        // diagnostic: phase stamps (never used for timing claims)
+    else if (trace) DSS_LAUNCH(true, false, false);
+    else if (ragged) DSS_LAUNCH(false, false, true);
+    else DSS_LAUNCH(false, false, false);
 #undef DSS_LAUNCH
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;

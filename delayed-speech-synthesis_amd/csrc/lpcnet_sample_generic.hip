@@ -42,6 +42,8 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
 {
     __shared__ __attribute__((aligned(16))) SampleLds L;
     const int utt = blockIdx.x;
+    const int slot = b.slot_of ? b.slot_of[utt] : utt;
+    const int nf = b.count_of ? min(b.count_of[utt], n_frames) : n_frames;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
 
@@ -50,8 +52,8 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
     for (int k = tid; k < NB * NB3; k += 512) L.gb_wrec[k] = m.gru_b_w_rec[k];
     if (tid < 201) L.tansig[tid] = m.tansig[tid];
     if (tid < 256) { L.ulaw2lin[tid] = m.ulaw2lin[tid]; L.logit_table[tid] = m.logit_table[tid]; }
-    if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)utt * NA + tid];
-    if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)utt * NB + tid];
+    if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)slot * NA + tid];
+    if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)slot * NB + tid];
 
     // GRU A per-unit constants (waves 0..5)
     float rbz = 0, rbr = 0, rbh = 0, dgz = 0, dgr = 0, dgh = 0;
@@ -83,10 +85,10 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
     DssKiss99 rng = {0, 0, 0, 0};
     if (wave == 7) {
 #pragma unroll
-        for (int j = 0; j < DSS_LPC_ORDER; ++j) last_sig[j] = b.last_sig[(size_t)utt * DSS_LPC_ORDER + j];
-        deemph = b.deemph[utt];
-        last_exc = b.last_exc[utt];
-        rng.z = b.rng[utt * 4 + 0]; rng.w = b.rng[utt * 4 + 1]; rng.jsr = b.rng[utt * 4 + 2]; rng.jcong = b.rng[utt * 4 + 3];
+        for (int j = 0; j < DSS_LPC_ORDER; ++j) last_sig[j] = b.last_sig[(size_t)slot * DSS_LPC_ORDER + j];
+        deemph = b.deemph[slot];
+        last_exc = b.last_exc[slot];
+        rng.z = b.rng[slot * 4 + 0]; rng.w = b.rng[slot * 4 + 1]; rng.jsr = b.rng[slot * 4 + 2]; rng.jcong = b.rng[slot * 4 + 3];
     } else {
 #pragma unroll
         for (int j = 0; j < DSS_LPC_ORDER; ++j) { last_sig[j] = 0; lpc[j] = 0; }
@@ -97,7 +99,7 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
     unsigned long long t_prev = 0;
     __syncthreads();
 
-    for (int f = 0; f < n_frames; ++f) {
+    for (int f = 0; f < nf; ++f) {
         short *pcm_frame = pcm_out + ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE;
         if (fc0 + f < DSS_FEATURES_DELAY) {                 // lpcnet.c: frame_count <= FEATURES_DELAY -> silence
             if (tid < DSS_FRAME_SIZE / 2) reinterpret_cast<int *>(pcm_frame)[tid] = 0;
@@ -263,14 +265,14 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
     if (STAMP && lane == 0 && b.trace_pcm) {        // diagnostic build only: per-wave phase cycle sums
         for (int k = 0; k < 6; ++k) b.trace_pcm[((size_t)utt * 8 + wave) * 6 + k] = (float)stamp_acc[k];
     }
-    if (tid < NA) b.gru_a_state[(size_t)utt * NA + tid] = L.state_a[cur][tid];
-    if (tid < NB) b.gru_b_state[(size_t)utt * NB + tid] = L.state_b[tid];
+    if (tid < NA) b.gru_a_state[(size_t)slot * NA + tid] = L.state_a[cur][tid];
+    if (tid < NB) b.gru_b_state[(size_t)slot * NB + tid] = L.state_b[tid];
     if (wave == 7 && lane == 0) {
 #pragma unroll
-        for (int j = 0; j < DSS_LPC_ORDER; ++j) b.last_sig[(size_t)utt * DSS_LPC_ORDER + j] = last_sig[j];
-        b.deemph[utt] = deemph;
-        b.last_exc[utt] = last_exc;
-        b.rng[utt * 4 + 0] = rng.z; b.rng[utt * 4 + 1] = rng.w; b.rng[utt * 4 + 2] = rng.jsr; b.rng[utt * 4 + 3] = rng.jcong;
+        for (int j = 0; j < DSS_LPC_ORDER; ++j) b.last_sig[(size_t)slot * DSS_LPC_ORDER + j] = last_sig[j];
+        b.deemph[slot] = deemph;
+        b.last_exc[slot] = last_exc;
+        b.rng[slot * 4 + 0] = rng.z; b.rng[slot * 4 + 1] = rng.w; b.rng[slot * 4 + 2] = rng.jsr; b.rng[slot * 4 + 3] = rng.jcong;
     }
 }
 

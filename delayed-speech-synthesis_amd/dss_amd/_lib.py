@@ -40,6 +40,8 @@ def _declare(L):
         "dss_lpcnet_batch_reset_async": (i, [vp, i, vp]),
         "dss_lpcnet_batch_synthesize": (i, [vp, vp, i, i, i, vp]),
         "dss_lpcnet_batch_synthesize_dev": (i, [vp, vp, i, i, i, vp, vp]),
+        "dss_lpcnet_batch_synthesize_ragged": (i, [vp, vp, vp, vp, i, i, i, vp]),
+        "dss_lpcnet_batch_synthesize_ragged_dev": (i, [vp, vp, vp, vp, i, i, i, vp, vp]),
         "dss_lpcnet_batch_tap": (i, [vp, i, i, vp, sz]),
         "dss_lpcnet_batch_enable_trace": (i, [vp, i]),
         "dss_lpcnet_batch_enable_timing": (i, [vp, i]),

@@ -97,6 +97,56 @@ class LPCNetBatch:
         _lib.check(self._L.dss_lpcnet_batch_synthesize_dev(self._h, features.data_ptr(), B, F, S, out.data_ptr(), s))
         return out
 
+    def synthesize_ragged(self, rows, slots=None, longest_first: bool = True):
+        """Utterances of different lengths in one launch.  ``rows``: sequence of (F_i, >=20) float32 host arrays;
+        ``slots[i]`` = decoder state continued by row i (default: slot i).  Returns a list of int16 arrays
+        (F_i*160,).  Rows are dispatched longest first (one workgroup per row, row order = dispatch order), so
+        when there are more rows than CUs the short ones fill in behind the long ones."""
+        n = len(rows)
+        if n == 0:
+            return []
+        counts = np.array([int(np.shape(r)[0]) for r in rows], dtype=np.int32)
+        slot_arr = np.arange(n, dtype=np.int32) if slots is None else np.asarray(slots, dtype=np.int32)
+        if slot_arr.shape != (n,):
+            raise ValueError("slots must have one entry per row")
+        fmax = int(counts.max())
+        if fmax == 0:
+            return [np.empty(0, dtype=np.int16) for _ in rows]
+        order = np.argsort(-counts, kind="stable") if longest_first else np.arange(n)
+        feats = np.zeros((n, fmax, NB_FEATURES), dtype=np.float32)
+        for k, i in enumerate(order):
+            if counts[i]:
+                r = np.asarray(rows[i], dtype=np.float32)
+                if r.ndim != 2 or r.shape[1] < NB_FEATURES:
+                    raise ValueError("each row must be (F_i, >=20)")
+                feats[k, :counts[i]] = r[:, :NB_FEATURES]
+        c_sorted = np.ascontiguousarray(counts[order])
+        s_sorted = np.ascontiguousarray(slot_arr[order])
+        pcm = np.empty((n, fmax * FRAME_SIZE), dtype=np.int16)
+        _lib.check(self._L.dss_lpcnet_batch_synthesize_ragged(self._h, feats.ctypes.data, s_sorted.ctypes.data,
+                                                              c_sorted.ctypes.data, n, fmax, NB_FEATURES, pcm.ctypes.data))
+        out = [None] * n
+        for k, i in enumerate(order):
+            out[i] = pcm[k, :counts[i] * FRAME_SIZE].copy()
+        return out
+
+    def synthesize_ragged_torch(self, features, counts, slots=None, out=None, stream=None):
+        """Device-resident ragged form: features CUDA float32 (n, Fmax, S>=20), ``counts``/``slots`` host int
+        sequences.  Returns the int16 CUDA tensor (n, Fmax*160); row i is valid up to counts[i]*160."""
+        import torch
+        assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        n, F, S = features.shape
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        sl = None if slots is None else np.ascontiguousarray(slots, dtype=np.int32)
+        if c.shape != (n,) or (sl is not None and sl.shape != (n,)):
+            raise ValueError("counts/slots must have one entry per row")
+        if out is None:
+            out = torch.empty((n, F * FRAME_SIZE), dtype=torch.int16, device=features.device)
+        s = torch.cuda.current_stream(features.device).cuda_stream if stream is None else stream
+        _lib.check(self._L.dss_lpcnet_batch_synthesize_ragged_dev(
+            self._h, features.data_ptr(), None if sl is None else sl.ctypes.data, c.ctypes.data, n, F, S, out.data_ptr(), s))
+        return out
+
     # ---- test / measurement taps ------------------------------------------------------------------------
     def enable_trace(self, on=True):
         _lib.check(self._L.dss_lpcnet_batch_enable_trace(self._h, int(on)))

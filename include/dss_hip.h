@@ -92,6 +92,21 @@ int dss_lpcnet_batch_synthesize(dss_lpcnet_batch *b, const float *features, int 
  * stream).  Nothing is copied to or from the host. */
 int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float *d_features, int n_utts, int n_frames,
                                     int feat_stride, short *d_pcm, void *hip_stream);
+/* Ragged / slot-indexed form.  Row i of the call (features [n_utts][n_frames][feat_stride], pcm
+ * [n_utts][n_frames*160]) continues the decoder state of slot slots[i] (NULL: slot i) and synthesizes
+ * only its first counts[i] <= n_frames frames (NULL: n_frames); its workgroup then retires, pcm beyond
+ * counts[i]*160 is left untouched and a count of 0 leaves the slot exactly as it was.  `slots` and
+ * `counts` are HOST arrays of n_utts ints, validated (range; a slot may appear once per call, a decoder is
+ * sequential) and uploaded on the stream.  This is the shape of the reference's real callers: .npy files
+ * of different lengths with a fresh decoder each (local/training.py:182-198), and speech segments of
+ * different lengths finishing on some of the 128 streams whose vocoder state carries across segments
+ * (local/units.py:524,531-538).  Workgroups are dispatched in row order: put long rows first when
+ * n_utts exceeds the 256 CUs.  Calls on one batch object must be issued on one stream at a time. */
+int dss_lpcnet_batch_synthesize_ragged_dev(dss_lpcnet_batch *b, const float *d_features, const int *slots,
+                                           const int *counts, int n_utts, int n_frames, int feat_stride,
+                                           short *d_pcm, void *hip_stream);
+int dss_lpcnet_batch_synthesize_ragged(dss_lpcnet_batch *b, const float *features, const int *slots,
+                                       const int *counts, int n_utts, int n_frames, int feat_stride, short *pcm);
 /* Test taps (device -> host): frame-rate network outputs of the LAST call, per utterance and frame:
  * which = 0: gru_a_condition [n_frames][3*gru_a]; 1: gru_b_condition [n_frames][3*gru_b]; 2: lpc [n_frames][16].
  * which = 3: per-sample excitation index (uint8 stored as float) [n_frames*160]; 4: pre-de-emphasis pcm float.

@@ -174,3 +174,55 @@ def test_batch_larger_than_the_chip(golden, model):
     pcm = LPCNetBatch(B, F).synthesize(feats)
     assert np.array_equal(pcm[0], g["utt2_pcm"]) and np.array_equal(pcm[598], g["utt2_pcm"])
     assert (pcm[1::2] == pcm[1]).all() and not np.array_equal(pcm[0], pcm[1])
+
+
+def test_ragged_rows_and_slot_indexed_state(oracle, model):
+    """dss_lpcnet_batch_synthesize_ragged: rows of different lengths in one launch, each continuing the decoder slot it
+    names -- the shape of the reference's real callers (files of different lengths, local/training.py:182-198;
+    segments finishing on some streams while the vocoder state carries across segments, local/units.py:524,531-538).
+    Checked per slot against one oracle decoder fed the same frames in the same order; a zero-frame row leaves its
+    slot untouched; both the fast and the generic kernel."""
+    from dss_amd.lpcnet import LPCNetBatch
+    calls = [                                         # (slot, first frame, number of frames) per row
+        [(3, 0, 2), (0, 0, 5), (4, 0, 1)],
+        [(0, 5, 4), (3, 2, 0), (1, 0, 3), (4, 1, 6)],
+        [(3, 2, 7), (1, 3, 1)],
+    ]
+    feats = {s: synthetic_features(900 + s, 12) for s in range(5)}
+    for force_generic in (False, True):
+        gpu = LPCNetBatch(5, 7)
+        if force_generic:
+            gpu.enable_trace(16)
+        decs = {s: oracle.decoder(model) for s in range(5)}
+        for rows in calls:
+            got = gpu.synthesize_ragged([feats[s][a:a + n] for s, a, n in rows], slots=[s for s, _, _ in rows])
+            for (s, a, n), pcm in zip(rows, got):
+                want = [decs[s].synthesize(feats[s][t]) for t in range(a, a + n)]
+                want = np.concatenate(want) if want else np.empty(0, np.int16)
+                assert pcm.shape == (n * 160,) and np.array_equal(pcm, want), (force_generic, s, a, n)
+
+
+def test_ragged_files_fresh_state_longest_first(golden, model):
+    """Offline shape: more files than CUs, different lengths, fresh decoder each; rows are dispatched longest first
+    and returned in the caller's order."""
+    from dss_amd.lpcnet import LPCNetBatch
+    g = golden("lpcnet_self.npz")
+    n = 300
+    lengths = [30 if i % 7 == 0 else 3 + (i % 11) for i in range(n)]
+    f2 = synthetic_features(2, 30)
+    got = LPCNetBatch(n, 30).synthesize_ragged([f2[:k] for k in lengths])
+    for k, pcm in zip(lengths, got):
+        assert np.array_equal(pcm, g["utt2_pcm"][:k * 160])
+
+
+def test_ragged_argument_errors(model):
+    from dss_amd import _lib
+    from dss_amd.lpcnet import LPCNetBatch
+    gpu = LPCNetBatch(4, 5)
+    f = synthetic_features(1, 5)
+    with pytest.raises(_lib.DssError, match="twice"):
+        gpu.synthesize_ragged([f, f], slots=[2, 2])
+    with pytest.raises(_lib.DssError, match="out of range"):
+        gpu.synthesize_ragged([f], slots=[4])
+    with pytest.raises(_lib.DssError, match="frames"):
+        gpu.synthesize_ragged([synthetic_features(1, 6)])
