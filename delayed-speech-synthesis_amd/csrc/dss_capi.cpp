@@ -992,3 +992,144 @@ extern "C" int dss_hga_extract_raw(dss_hga *h, const double *raw, int n, double 
     for (size_t k = 0; k < cnt; ++k) out[k] = log(out[k]);                 // pyx:46, host libm (DESIGN.md "HGA log")
     return W;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// speech-segment gate (Part 4 of include/dss_hip.h)
+// ------------------------------------------------------------------------------------------------------
+struct dss_gate {
+    int device;
+    int max_frames;
+    DssGateDev d;
+    double *d_frames = nullptr;   // staging of the host-buffer entry point
+    int *d_labels = nullptr;
+    std::vector<int> last_events; // host copy of the last push's event records
+};
+
+extern "C" dss_gate *dss_gate_create(int n_streams, int nb_features, int smoothing_context, double proportion_threshold,
+                                     int buffer_size, int context, int max_frames)
+{
+    if (n_streams <= 0 || nb_features <= 0 || smoothing_context < 0 || 2 * smoothing_context + 1 > 64 || buffer_size <= 0 ||
+        context < 0 || max_frames <= 0) {
+        dss_set_error("bad gate arguments (smoothing window 2*ctx+1 must be <= 64)");
+        return nullptr;
+    }
+    if (ensure_device()) return nullptr;
+    dss_gate *g = new dss_gate;
+    g->device = g_device;
+    g->max_frames = max_frames;
+    DssGateDev &d = g->d;
+    memset(&d, 0, sizeof(d));
+    d.S = n_streams; d.C = nb_features; d.sm_ctx = smoothing_context; d.sm_size = 2 * smoothing_context + 1;
+    d.hist_size = buffer_size; d.hist_ctx = context; d.threshold = proportion_threshold;
+    // a segment closes on the context-th non-speech frame after >= 1 speech frame: at most one per (context + 1)
+    // frames, or one per 2 frames without context
+    d.max_events = context > 0 ? max_frames / (context + 1) + 1 : (max_frames + 1) / 2;
+    const size_t S = n_streams, C = nb_features;
+    int rc = dev_alloc<float>(S * d.sm_size * C, &d.sm_buf);
+    rc |= dev_alloc<float>(S * d.hist_size * C, &d.hist);
+    rc |= dev_alloc<float>(S * d.max_events * d.hist_size * C, &d.seg_out);
+    rc |= dev_alloc<int>(S * DSS_GATE_STATE_INTS, &d.state);
+    rc |= dev_alloc<int>(S * (2 + d.max_events), &d.events);
+    rc |= dev_alloc<double>(S * max_frames * C, &g->d_frames);
+    rc |= dev_alloc<int>(S * max_frames, &g->d_labels);
+    if (!rc) rc = dss_launch_gate_reset(d, -1, 0);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = DSS_ENODEV;
+    if (rc) { dss_set_error("gate device setup failed"); delete g; return nullptr; }
+    g->last_events.assign(S * (2 + d.max_events), 0);
+    return g;
+}
+
+extern "C" void dss_gate_destroy(dss_gate *g)
+{
+    if (!g) return;
+    hipSetDevice(g->device);
+    void *ptrs[] = {g->d.sm_buf, g->d.hist, g->d.seg_out, g->d.state, g->d.events, g->d_frames, g->d_labels};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete g;
+}
+
+extern "C" int dss_gate_max_events(const dss_gate *g) { return g ? g->d.max_events : DSS_EINVAL; }
+
+extern "C" int dss_gate_reset(dss_gate *g, int stream)
+{
+    if (!g || stream >= g->d.S) { dss_set_error("bad gate/stream"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(g->device));
+    int rc = dss_launch_gate_reset(g->d, stream, 0);
+    if (rc) return rc;
+    DSS_HIP_CHECK(hipStreamSynchronize(0));
+    return DSS_OK;
+}
+
+extern "C" int dss_gate_push_dev(dss_gate *g, const double *d_frames, const int *d_labels, int n_frames, int *events,
+                                 void *hip_stream)
+{
+    if (!g || !d_frames || !d_labels || !events) { dss_set_error("null argument"); return DSS_EINVAL; }
+    if (n_frames <= 0 || n_frames > g->max_frames) { dss_set_error("%d frames per push outside [1, %d]", n_frames, g->max_frames); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(g->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    int rc = dss_launch_gate(g->d, d_frames, d_labels, n_frames, s);
+    if (rc) return rc;
+    const size_t n = (size_t)g->d.S * (2 + g->d.max_events);
+    DSS_HIP_CHECK(hipMemcpyAsync(g->last_events.data(), g->d.events, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    DSS_HIP_CHECK(hipStreamSynchronize(s));
+    int total = 0;
+    for (int st = 0; st < g->d.S; ++st) {
+        const int ne = g->last_events[(size_t)st * (2 + g->d.max_events)];
+        if (ne > g->d.max_events) { dss_set_error("stream %d completed %d segments in one push (capacity %d)", st, ne, g->d.max_events); return DSS_EINVAL; }
+        total += ne;
+    }
+    memcpy(events, g->last_events.data(), n * sizeof(int));
+    return total;
+}
+
+extern "C" int dss_gate_push(dss_gate *g, const double *frames, const int *labels, int n_frames, int *events)
+{
+    if (!g || !frames || !labels || !events) { dss_set_error("null argument"); return DSS_EINVAL; }
+    if (n_frames <= 0 || n_frames > g->max_frames) { dss_set_error("%d frames per push outside [1, %d]", n_frames, g->max_frames); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(g->device));
+    DSS_HIP_CHECK(hipMemcpy(g->d_frames, frames, sizeof(double) * g->d.S * n_frames * g->d.C, hipMemcpyHostToDevice));
+    DSS_HIP_CHECK(hipMemcpy(g->d_labels, labels, sizeof(int) * g->d.S * n_frames, hipMemcpyHostToDevice));
+    return dss_gate_push_dev(g, g->d_frames, g->d_labels, n_frames, events, nullptr);
+}
+
+static int gate_segment_src(dss_gate *g, int stream, int event, int cap_frames, const float **src, int *len)
+{
+    if (!g || stream < 0 || stream >= g->d.S || event < 0) { dss_set_error("bad gate/stream/event"); return DSS_EINVAL; }
+    const int *ev = &g->last_events[(size_t)stream * (2 + g->d.max_events)];
+    if (event >= ev[0]) { dss_set_error("stream %d completed %d segments in the last push, asked for #%d", stream, ev[0], event); return DSS_EINVAL; }
+    *len = ev[2 + event];
+    if (*len > cap_frames) { dss_set_error("segment has %d frames, buffer holds %d", *len, cap_frames); return DSS_EINVAL; }
+    *src = g->d.seg_out + ((size_t)stream * g->d.max_events + event) * (size_t)g->d.hist_size * g->d.C;
+    return DSS_OK;
+}
+
+extern "C" int dss_gate_segment_dev(dss_gate *g, int stream, int event, float *d_dst, int cap_frames, void *hip_stream)
+{
+    const float *src; int len;
+    int rc = gate_segment_src(g, stream, event, cap_frames, &src, &len);
+    if (rc) return rc;
+    if (!d_dst) { dss_set_error("null argument"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(g->device));
+    if (len) DSS_HIP_CHECK(hipMemcpyAsync(d_dst, src, sizeof(float) * (size_t)len * g->d.C, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    return len;
+}
+
+extern "C" int dss_gate_segment(dss_gate *g, int stream, int event, float *dst, int cap_frames)
+{
+    const float *src; int len;
+    int rc = gate_segment_src(g, stream, event, cap_frames, &src, &len);
+    if (rc) return rc;
+    if (!dst) { dss_set_error("null argument"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(g->device));
+    if (len) DSS_HIP_CHECK(hipMemcpy(dst, src, sizeof(float) * (size_t)len * g->d.C, hipMemcpyDeviceToHost));
+    return len;
+}
+
+extern "C" int dss_gate_frames_seen(dss_gate *g, int stream)
+{
+    if (!g || stream < 0 || stream >= g->d.S) { dss_set_error("bad gate/stream"); return DSS_EINVAL; }
+    if (hipSetDevice(g->device) != hipSuccess) return DSS_ENODEV;
+    int v = 0;
+    if (hipMemcpy(&v, g->d.state + (size_t)stream * DSS_GATE_STATE_INTS + 7, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return DSS_ENODEV;
+    return v;
+}

@@ -121,6 +121,23 @@ int dss_launch_sample_network_generic(const DssModelDev &m, DssBatchDev &b, int 
                                       int trace, hipStream_t s);
 int dss_launch_lpcnet_reset(const DssModelDev &m, DssBatchDev &b, int utt, hipStream_t s);
 
+// ---- speech-segment gate (speech_gate.hip) ---------------------------------------------------------------
+#define DSS_GATE_STATE_INTS 8     // sm_write, sm_read, hist_write, speech_count, future_count, mask_lo, mask_hi, frames_seen
+struct DssGateDev {
+    int S, C;
+    int sm_ctx, sm_size;          // smoothing context frames, window = 2*ctx+1 (<= 64)
+    int hist_size, hist_ctx;      // segment ring length, context frames kept on both sides of a speech run
+    int max_events;               // segments one stream can complete in one push
+    double threshold;             // proportion of speech labels in the window that makes a frame speech
+    float *sm_buf;                // [S][sm_size][C]
+    float *hist;                  // [S][hist_size][C]
+    float *seg_out;               // [S][max_events][hist_size][C] completed segments of the last push
+    int *state;                   // [S][DSS_GATE_STATE_INTS]
+    int *events;                  // [S][2 + max_events]: n_events, n_speech_labels, lengths
+};
+int dss_launch_gate(const DssGateDev &g, const double *d_frames, const int *d_labels, int W, hipStream_t s);
+int dss_launch_gate_reset(const DssGateDev &g, int stream, hipStream_t s);
+
 struct DssHgaDev {
     int S, C, fs, nsec;
     float wl, ws;

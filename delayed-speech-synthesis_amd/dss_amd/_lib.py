@@ -46,6 +46,15 @@ def _declare(L):
         "dss_lpcnet_batch_enable_trace": (i, [vp, i]),
         "dss_lpcnet_batch_enable_timing": (i, [vp, i]),
         "dss_lpcnet_batch_kernel_ms": (C.c_double, [vp, i]),
+        "dss_gate_create": (vp, [i, i, i, C.c_double, i, i, i]),
+        "dss_gate_destroy": (None, [vp]),
+        "dss_gate_reset": (i, [vp, i]),
+        "dss_gate_max_events": (i, [vp]),
+        "dss_gate_push": (i, [vp, vp, vp, i, vp]),
+        "dss_gate_push_dev": (i, [vp, vp, vp, i, vp, vp]),
+        "dss_gate_segment": (i, [vp, i, i, vp, i]),
+        "dss_gate_segment_dev": (i, [vp, i, i, vp, i, vp]),
+        "dss_gate_frames_seen": (i, [vp, i]),
         "dss_hga_num_windows": (i, [i, i, f, f]),
         "dss_hga_log_power": (i, [vp, i, i, i, f, f, vp]),
         "dss_hga_create": (vp, [i, i, i, f, f, i, vp, vp, vp, vp]),

@@ -3,6 +3,11 @@
 ``SegmentPipeline``   config 3: a batch of 64-channel ECoG segments -> HGA frames -> z-score -> BiLSTM decoder
                       (PyTorch-ROCm, reference local/models.py) -> LPCNet -> 16 kHz PCM.  Nothing leaves HBM
                       between the stages.
+``GatedStreamingPipeline`` config 5 with the reference's segment gating (decode_online.py): the neural VAD runs on
+                      all streams' frames at once, the smoothing and segment ring buffers live on the device
+                      (csrc/speech_gate.hip), and only completed speech segments are decoded (whole-segment BiLSTM,
+                      as the reference does) and synthesised -- one ragged LPCNet launch per tick for the streams
+                      whose segment just closed, each continuing that stream's vocoder state.
 ``StreamingPipeline`` config 5: S concurrent streams advanced one amplifier packet (40 samples = 4 frames) at a
                       time; HGA filter state, frame overlap and LPCNet decoder state persist per stream.  The
                       bidirectional decoder is whole-segment in the reference (units.py:499-508); here it runs on
@@ -17,6 +22,7 @@ from typing import Optional
 import numpy as np
 import torch
 
+from .gate import SpeechGateGPU
 from .hga import HgaExtractorGPU
 from .lpcnet import FRAME_SIZE, LPCNetBatch
 
@@ -88,3 +94,71 @@ class StreamingPipeline(_DecoderMixin):
             self.push(pk)
             lat.append((time.perf_counter() - t0) * 1e3)
         return np.asarray(lat)
+
+
+class GatedStreamingPipeline(_DecoderMixin):
+    """S streams through HighGammaActivity -> FilterSpeechSegments -> RecurrentNeuralDecodingModel ->
+    DelayedLPCNetVocoder (decode_online.py:115-135), all streams per tick in batched launches."""
+
+    def __init__(self, n_streams: int, n_channels: int = 64, fs: int = 1000, packet: int = 40,
+                 buffer_size: int = 2000, context_frames: int = 50, smoothing_context: int = 5,
+                 channel_means: Optional[np.ndarray] = None, channel_stds: Optional[np.ndarray] = None,
+                 decoder: Optional[torch.nn.Module] = None, vad: Optional[torch.nn.Module] = None, seed: int = 0,
+                 max_segment_frames: Optional[int] = None):
+        self.S, self.C, self.packet = n_streams, n_channels, packet
+        self.hga = HgaExtractorGPU(n_streams, n_channels, fs=fs)
+        self.decoder = self._make_decoder(n_channels, decoder, seed)
+        if vad is None:
+            from local.models import UnidirectionalVoiceActivityDetector
+            torch.manual_seed(seed + 1)     # no trained checkpoint exists offline: seeded random weights
+            vad = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=n_channels)
+        self.vad = vad.eval().cuda()
+        self.vad_state = self.vad.create_new_initial_state(batch_size=n_streams, device="cuda")
+        max_w = packet // max(1, int(0.01 * fs)) + 1      # frames one packet can complete (10 ms shift)
+        self.gate = SpeechGateGPU(n_streams, n_channels, buffer_size, context_frames, smoothing_context, 0.6, max_frames=max_w)
+        self.seg_cap = int(max_segment_frames or buffer_size)
+        self.vocoder = LPCNetBatch(n_streams, self.seg_cap)       # slot = stream: vocoder state carries across segments
+        mean = np.zeros(n_channels) if channel_means is None else np.asarray(channel_means, dtype=np.float64)
+        std = np.ones(n_channels) if channel_stds is None else np.asarray(channel_stds, dtype=np.float64)
+        self.mean, self.std = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
+        self._in = torch.empty((n_streams, packet, n_channels), dtype=torch.float64, device="cuda")
+        self.frame_counter = 0
+        self.last_labels = None           # raw VAD decisions and z-scored frames of the last tick (test taps)
+        self.last_z = None
+
+    @torch.no_grad()
+    def push(self, packets: np.ndarray):
+        """packets: host float64 (S, packet, C).  Returns a list of (stream, previous_frames, pcm int16 host array)
+        for every speech segment that closed on this tick (usually empty)."""
+        self._in.copy_(torch.from_numpy(np.ascontiguousarray(packets, dtype=np.float64)))
+        hga = self.hga.extract_torch(self._in, apply_log=True)                       # (S, W, C) float64
+        W = hga.shape[1]
+        if W == 0:
+            return []
+        z = ((hga - self.mean) / self.std).contiguous()                               # post-transform (ZScoreNormalization)
+        logits, self.vad_state = self.vad(z.to(torch.float32), self.vad_state)       # units.py:433-434
+        labels = torch.argmax(logits, dim=2).to(torch.int32).contiguous()
+        self.last_labels, self.last_z = labels, z
+        events = self.gate.push_torch(z, labels)
+        self.frame_counter += W
+        out = []
+        for e in range(self.gate.E):                     # a stream closes at most one segment per tick in practice
+            streams = [s for s in range(self.S) if events[s, 0] > e]
+            if not streams:
+                break
+            counts = [int(events[s, 2 + e]) for s in streams]
+            fmax = max(counts)
+            if fmax > self.seg_cap:
+                raise ValueError(f"segment of {fmax} frames exceeds max_segment_frames={self.seg_cap}")
+            feats = torch.zeros((len(streams), max(fmax, 1), 20), dtype=torch.float32, device="cuda")
+            for k, s in enumerate(streams):              # whole-segment bidirectional decode, fresh state (units.py:499-508)
+                if counts[k] == 0:
+                    continue
+                seg = self.gate.segment_torch(s, e)
+                y, _ = self.decoder(seg[None], self.decoder.create_new_initial_state(batch_size=1, device="cuda"))
+                feats[k, :counts[k]] = y[0]
+            pcm = self.vocoder.synthesize_ragged_torch(feats, counts, slots=streams).cpu().numpy()
+            for k, s in enumerate(streams):
+                previous = self.frame_counter - counts[k] - (W - int(events[s, 1]))    # units.py:445
+                out.append((s, previous, pcm[k, :counts[k] * FRAME_SIZE].copy()))
+        return out

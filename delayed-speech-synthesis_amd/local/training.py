@@ -15,7 +15,7 @@ logger = logging.getLogger("training.py")
 
 
 class AsynchronousSynthesisQueue:
-    MAX_BATCH = 256
+    MAX_BATCH = 1024        # files per launch (config 4's per-GPU share); 256 run at once, the rest queue behind them
 
     def __init__(self, nb_processes: int = 0):
         # nb_processes is accepted for signature compatibility; parallelism comes from the GPU batch
@@ -54,13 +54,11 @@ class AsynchronousSynthesisQueue:
                 logger.error(f"Could not synthesize {name} due to an unexpected exceptions: {str(e)}")
         if not loaded:
             return
-        loaded.sort(key=lambda it: it[1].shape[0])
+        # one ragged launch per MAX_BATCH files: every file gets a fresh decoder (training.py:193) and its own frame
+        # count; rows are dispatched longest first so short files fill in behind long ones
         for a in range(0, len(loaded), self.MAX_BATCH):
             chunk = loaded[a:a + self.MAX_BATCH]
             frames = max(f.shape[0] for _, f in chunk)
-            batch = np.zeros((len(chunk), frames, 20), dtype=np.float32)     # zero-padded tails are discarded:
-            for i, (_, f) in enumerate(chunk):                                 # synthesis is causal
-                batch[i, : f.shape[0]] = f
-            pcm = LPCNetBatch(len(chunk), frames).synthesize(batch)            # fresh decoder per utterance
-            for i, (name, f) in enumerate(chunk):
-                wavwrite(Path(name).with_suffix(".wav").as_posix(), 16000, pcm[i, : f.shape[0] * 160])
+            pcm = LPCNetBatch(len(chunk), frames).synthesize_ragged([f for _, f in chunk])
+            for (name, _), wav in zip(chunk, pcm):
+                wavwrite(Path(name).with_suffix(".wav").as_posix(), 16000, wav)

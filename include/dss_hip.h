@@ -161,6 +161,40 @@ int dss_hga_extract_raw_dev(dss_hga *h, const double *d_raw, int n, double *d_ou
  * from the host's) when apply_log != 0, else out = mean power + 0.01. */
 int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, int apply_log, void *hip_stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Part 4 -- speech-segment gate for n_streams streams: the two ring buffers the
+ * reference chains behind its neural VAD in FilterSpeechSegments.process (local/units.py:432-447):
+ * VoiceActivityDetectionSmoothing (local/common.py:106-153; window 2*smoothing_context+1 <= 64 labels,
+ * a frame is speech when the proportion of raw speech labels in the window >= proportion_threshold) and
+ * SpeechSegmentHistory (local/common.py:156-215; ring of buffer_size float32 frames, a segment is the
+ * speech run plus `context` frames on both sides, emitted on the context-th non-speech frame after it).
+ * The VAD network itself stays on PyTorch-ROCm (north_star); its per-frame decisions come in as int32.
+ * decode_online.py:115-121 uses smoothing_context 5 (units.py:416), threshold 0.6, buffer 2000, context 50.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dss_gate dss_gate;
+dss_gate *dss_gate_create(int n_streams, int nb_features, int smoothing_context, double proportion_threshold,
+                          int buffer_size, int context, int max_frames /* per push */);
+void dss_gate_destroy(dss_gate *g);
+int dss_gate_reset(dss_gate *g, int stream /* -1: all */);
+/* Segments one stream can complete within one push of max_frames frames (E below). */
+int dss_gate_max_events(const dss_gate *g);
+/* All streams advance by n_frames: frames (n_streams, n_frames, nb_features) float64 (msg.data as the unit
+ * receives it; stored as float32 like the numpy rings), labels (n_streams, n_frames) int32, nonzero = the
+ * VAD's argmax said speech.  events (HOST out, n_streams x (2+E) ints): per stream [number of segments
+ * completed in this push, number of frames the smoothing labelled speech in this push (units.py:445 needs
+ * it for previous_frames), length of segment 0, ...].  Returns the total number of completed segments
+ * (>= 0) or a negative error.  _dev: device pointers, enqueued on hip_stream, which is synchronised
+ * before returning (the caller needs the event counts to go on). */
+int dss_gate_push(dss_gate *g, const double *frames, const int *labels, int n_frames, int *events);
+int dss_gate_push_dev(dss_gate *g, const double *d_frames, const int *d_labels, int n_frames, int *events,
+                      void *hip_stream);
+/* Copy segment `event` that `stream` completed in the LAST push: (length, nb_features) float32, at most
+ * cap_frames rows.  Returns its length. */
+int dss_gate_segment(dss_gate *g, int stream, int event, float *dst, int cap_frames);
+int dss_gate_segment_dev(dss_gate *g, int stream, int event, float *d_dst, int cap_frames, void *hip_stream);
+/* Frames this stream has been pushed since the last reset (FilterSpeechSegments' frame_counter). */
+int dss_gate_frames_seen(dss_gate *g, int stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,141 @@
+"""GPU tests of the speech-segment gate: csrc/speech_gate.hip through the C ABI against the
+numpy ring-buffer classes of local/common.py (themselves pinned by hand-derived known answers in test_cpu_local.py),
+and the gated many-stream pipeline against the per-stream composition the reference's graph performs."""
+import asyncio
+
+import numpy as np
+import pytest
+import torch
+
+from dss_amd.lpcnet_weights import synthetic_blob
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_gate(C, N, ctx, sm_ctx):
+    from local.common import SpeechSegmentHistory, VoiceActivityDetectionSmoothing
+    return (VoiceActivityDetectionSmoothing(nb_features=C, context_frames=sm_ctx),
+            SpeechSegmentHistory(nb_features=C, buffer_size=N, context=ctx))
+
+
+@pytest.mark.parametrize("C,N,ctx,sm_ctx", [(64, 2000, 50, 5), (5, 37, 3, 2), (70, 16, 0, 0), (3, 23, 4, 1)])
+def test_gate_matches_numpy_rings_bit_exact(C, N, ctx, sm_ctx):
+    """Random label runs over many pushes of ragged size: same segments (float32 rows, bit for bit), same lengths, same
+    speech counts -- including rings that wrap and speech runs longer than the ring (the classes' modulo arithmetic)."""
+    from dss_amd.gate import SpeechGateGPU
+    S, WMAX = 6, 7
+    rng = np.random.default_rng(C * 1000 + N)
+    gate = SpeechGateGPU(S, C, N, ctx, sm_ctx, 0.6, max_frames=WMAX)
+    host = [_host_gate(C, N, ctx, sm_ctx) for _ in range(S)]
+    state = rng.integers(0, 2, S)                       # label runs: flip with a per-stream probability
+    p_flip = np.array([0.02, 0.05, 0.1, 0.2, 0.4, 0.01])
+    n_seg = 0
+    for tick in range(260):
+        W = int(rng.integers(1, WMAX + 1))
+        frames = rng.standard_normal((S, W, C)) * 3.0
+        labels = np.zeros((S, W), dtype=np.int64)
+        for i in range(W):
+            state = np.where(rng.random(S) < p_flip, 1 - state, state)
+            labels[:, i] = state
+        got, n_speech = gate.push(frames, labels)
+        for s in range(S):
+            sm, hist = host[s]
+            data, lab = sm.insert(data=frames[s], speech_labels=labels[s])
+            want = hist.insert(data=data, speech_labels=lab)
+            assert len(got[s]) == len(want), (tick, s)
+            assert n_speech[s] == np.count_nonzero(lab)
+            for a, b in zip(got[s], want):
+                assert a.dtype == np.float32 and a.shape == b.shape and np.array_equal(a, b), (tick, s)
+            n_seg += len(want)
+    assert n_seg > 20
+    assert gate.frames_seen(0) > 0
+
+
+def test_gate_reset_one_stream_and_errors():
+    from dss_amd import _lib
+    from dss_amd.gate import SpeechGateGPU
+    gate = SpeechGateGPU(2, 4, 32, 2, 1, 0.6, max_frames=6)
+    f = np.ones((2, 6, 4))
+    lab = np.array([[1, 1, 1, 1, 0, 0]] * 2)
+    gate.push(f, lab)
+    gate.reset(1)
+    assert gate.frames_seen(0) == 6 and gate.frames_seen(1) == 0
+    segs, _ = gate.push(np.ones((2, 3, 4)), np.zeros((2, 3)))
+    assert len(segs[0]) == 1 and len(segs[1]) == 0          # stream 0 closes its run, stream 1 forgot it
+    with pytest.raises(_lib.DssError, match="frames per push"):
+        gate.push(np.ones((2, 7, 4)), np.zeros((2, 7)))
+    with pytest.raises(_lib.DssError, match="<= 64"):
+        SpeechGateGPU(1, 4, 32, 2, 40)
+
+
+class _ThresholdVAD(torch.nn.Module):
+    """Stands in for a trained VAD checkpoint (none exists offline): speech when the first z-scored feature is positive.
+    Same call surface as local.models.UnidirectionalVoiceActivityDetector."""
+
+    def create_new_initial_state(self, batch_size, device="cpu", req_grad=False):
+        return (torch.zeros(1, batch_size, 1, device=device), torch.zeros(1, batch_size, 1, device=device))
+
+    def forward(self, x, state=None):
+        return torch.stack([torch.zeros_like(x[..., 0]), x[..., 0]], dim=-1), state
+
+
+def test_gated_streaming_pipeline_against_per_stream_composition(oracle):
+    """decode_online.py's chain for several streams at once: segments, previous_frames and PCM per stream equal what the
+    single-stream units / numpy classes / the vocoder oracle produce from the same frames, with the vocoder state of a
+    stream carried from one of its segments to the next."""
+    import local.units as U
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import GatedStreamingPipeline
+    blob = synthetic_blob(0)
+    lpcnet.load_model(blob)
+    model = oracle.lpcnet_model(blob)
+    S, C, ticks = 3, 64, 70
+    rng = np.random.default_rng(7)
+    # ECoG whose amplitude alternates between quiet and loud stretches, so that log power crosses the z-score mean
+    env = np.ones((S, ticks * 40))
+    for s in range(S):
+        t = 0
+        loud = False
+        while t < env.shape[1]:
+            n = int(rng.integers(150, 500))
+            env[s, t:t + n] = 400.0 if loud else 20.0
+            loud = not loud
+            t += n
+    ecog = rng.standard_normal((S, ticks * 40, C)) * env[:, :, None]
+    mean = np.full(C, 7.4)                              # between the two stretches' log band power (about 4.4 and 10.4)
+    pipe = GatedStreamingPipeline(S, C, buffer_size=300, context_frames=8, channel_means=mean, vad=_ThresholdVAD(),
+                                  max_segment_frames=300)
+    host = [_host_gate(C, 300, 8, 5) for _ in range(S)]
+    vocoders = [oracle.decoder(model) for _ in range(S)]
+    unit = U.FilterSpeechSegments(U.FilterSpeechSegmentsSettings(nb_features=C, fs=1000, vad_architecture=_ThresholdVAD,
+                                                                 buffer_size=300, context_frames=8))
+    unit.initialize()
+
+    async def drive(gen):
+        return [m async for m in gen]
+
+    counter, n_seg = 0, 0
+    for k in range(ticks):
+        got = pipe.push(ecog[:, k * 40:(k + 1) * 40])
+        z, labels = pipe.last_z.cpu().numpy(), pipe.last_labels.cpu().numpy()
+        W = z.shape[1]
+        counter += W
+        want = []
+        for s in range(S):
+            data, lab = host[s][0].insert(data=z[s], speech_labels=labels[s])
+            for seg in host[s][1].insert(data=data, speech_labels=lab):
+                with torch.no_grad():
+                    y, _ = pipe.decoder(torch.from_numpy(seg)[None].cuda(),
+                                        pipe.decoder.create_new_initial_state(batch_size=1, device="cuda"))
+                feats = y[0].cpu().numpy()
+                pcm = np.concatenate([vocoders[s].synthesize(feats[t]) for t in range(len(feats))])
+                want.append((s, counter - len(seg) - (W - np.count_nonzero(lab)), pcm))
+        assert [(s, p) for s, p, _ in got] == [(s, p) for s, p, _ in want], k
+        for (_, _, a), (_, _, b) in zip(got, want):
+            assert a.dtype == np.int16 and np.array_equal(a, b), k
+        n_seg += len(want)
+        # stream 0 through the single-stream unit: same segments and bookkeeping
+        msgs = asyncio.run(drive(unit.process(U.ClosedLoopMessage(data=z[0], fs=100))))
+        mine = [(p, len(a) // 160) for s, p, a in got if s == 0]
+        assert [(m.previous_frames, len(m.data)) for _, m in msgs] == mine, k
+    assert n_seg >= 6
