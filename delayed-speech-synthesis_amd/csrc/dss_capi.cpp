@@ -472,7 +472,7 @@ struct dss_lpcnet_batch {
     short *d_pcm = nullptr;
     int *d_slots = nullptr;       // [max_utts] slot list of a ragged call
     int *d_counts = nullptr;      // [max_utts] frame counts of a ragged call
-    hipEvent_t ev[3];
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     double ms_sum[2] = {0, 0};
     int ms_n = 0;
 };
@@ -513,8 +513,12 @@ extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frame
     rc |= dev_alloc<int>(B, &b->d_slots);
     rc |= dev_alloc<int>(B, &b->d_counts);
     for (int i = 0; i < 3; ++i) rc |= (hipEventCreate(&b->ev[i]) != hipSuccess);
-    if (rc) { dss_set_error("device allocation failed for batch %d x %d", max_utts, max_frames); delete b; return nullptr; }
-    if (dss_launch_lpcnet_reset(*m, d, -1, 0) || hipDeviceSynchronize() != hipSuccess) { delete b; return nullptr; }
+    if (rc) {
+        dss_set_error("device allocation failed for batch %d x %d", max_utts, max_frames);
+        dss_lpcnet_batch_destroy(b);
+        return nullptr;
+    }
+    if (dss_launch_lpcnet_reset(*m, d, -1, 0) || hipDeviceSynchronize() != hipSuccess) { dss_lpcnet_batch_destroy(b); return nullptr; }
     return b;
 }
 
@@ -527,7 +531,7 @@ extern "C" void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b)
                     d.conv2_mem, d.old_lpc, d.in_buf, d.c1_buf, d.c2_buf, d.d1_buf, d.cond_buf, d.lpc_buf, d.frame_out,
                     d.fc0, d.trace_exc, d.trace_pcm, b->d_feat, b->d_pcm, b->d_slots, b->d_counts};
     for (void *p : ptrs) if (p) hipFree(p);
-    for (int i = 0; i < 3; ++i) hipEventDestroy(b->ev[i]);
+    for (int i = 0; i < 3; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
     delete b;
 }
 
@@ -847,7 +851,7 @@ extern "C" dss_hga *dss_hga_create(int n_streams, int n_channels, int fs, float 
     if (!rc) rc = hga_grow_rows(h, d.overlap + 4 * d.frame_length);
     if (!rc) rc = dss_launch_hga_reset(d, h->d_zi0[0], h->d_zi0[1], 0);
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = DSS_ENODEV;
-    if (rc) { dss_set_error("HGA device setup failed"); delete h; return nullptr; }
+    if (rc) { dss_set_error("HGA device setup failed"); dss_hga_destroy(h); return nullptr; }
     return h;
 }
 
@@ -1034,7 +1038,7 @@ extern "C" dss_gate *dss_gate_create(int n_streams, int nb_features, int smoothi
     rc |= dev_alloc<int>(S * max_frames, &g->d_labels);
     if (!rc) rc = dss_launch_gate_reset(d, -1, 0);
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = DSS_ENODEV;
-    if (rc) { dss_set_error("gate device setup failed"); delete g; return nullptr; }
+    if (rc) { dss_set_error("gate device setup failed"); dss_gate_destroy(g); return nullptr; }
     g->last_events.assign(S * (2 + d.max_events), 0);
     return g;
 }

@@ -152,6 +152,9 @@ struct SampleLds {
 #define DSS_GB_LOAD(AV, AN, G)                                                                   \
     _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
         (AV)[u] = *reinterpret_cast<const f32x4 *>((AN) + 16 * (G) + 4 * u);
+// One s_waitcnt per group of four reads instead of the compiler's one per read (gfx9 encoding, vmcnt/expcnt left at
+// their maxima): a wave issues about one instruction per 5 cycles whatever its kind, waits included.
+#define DSS_WAIT_LGKM(N) __builtin_amdgcn_s_waitcnt(0xC07F | ((N) << 8))
 #define DSS_GB_CHAIN(AN, N)                                                                      \
     {                                                                                            \
         f32x4 avA[4], avB[4];                                                                    \
@@ -159,11 +162,17 @@ struct SampleLds {
         _Pragma("unroll") for (int g = 0; g < (N) / 16; g += 2) {                                \
             if (g + 1 < (N) / 16) DSS_GB_LOAD(avB, AN, g + 1)                                    \
             __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch ahead of the arithmetic */ \
+            if (g + 1 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                       \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
             DSS_GB_GROUP(avA, g)                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                   \
             if (g + 2 < (N) / 16) DSS_GB_LOAD(avA, AN, g + 2)                                    \
             __builtin_amdgcn_sched_barrier(0);                                                   \
-            if (g + 1 < (N) / 16) DSS_GB_GROUP(avB, g + 1)                                       \
+            if (g + 1 < (N) / 16) {                                                              \
+                if (g + 2 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                   \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                DSS_GB_GROUP(avB, g + 1)                                                         \
+            }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
     }
@@ -528,11 +537,17 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     for (int g = 0; g < GBHL / 8; g += 2) {
                         if (g + 1 < GBHL / 8) DSS_GBL_LOAD(tB, g + 1)
                         __builtin_amdgcn_sched_barrier(0);
+                        if (g + 1 < GBHL / 8) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);
+                        __builtin_amdgcn_sched_barrier(0);
                         DSS_GBL_GROUP(tA)
                         __builtin_amdgcn_sched_barrier(0);
                         if (g + 2 < GBHL / 8) DSS_GBL_LOAD(tA, g + 2)
                         __builtin_amdgcn_sched_barrier(0);
-                        if (g + 1 < GBHL / 8) DSS_GBL_GROUP(tB)
+                        if (g + 1 < GBHL / 8) {
+                            if (g + 2 < GBHL / 8) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            DSS_GBL_GROUP(tB)
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -606,15 +621,17 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
     // two register-slot capacities are compiled: 10 per gate (no spills) and 12 (a few spilled registers)
     const bool z10 = m.nzr_max <= 10;
-    static bool attr_set = false;
-    if (!attr_set) {      // one workgroup uses (almost) the whole 160 KB of the CU
+    static unsigned long long attr_set = 0;     // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    DSS_HIP_CHECK(hipGetDevice(&dev));
+    if (!(attr_set >> (dev & 63) & 1)) {      // one workgroup uses (almost) the whole 160 KB of the CU
 #define DSS_SET_ATTR(K) DSS_HIP_CHECK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES))
         DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, false>)); DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, false>));
         DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, true>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, true>));
         DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 10, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 12, false>));
         DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 10, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 12, false>));
 #undef DSS_SET_ATTR
-        attr_set = true;
+        attr_set |= 1ull << (dev & 63);
     }
     const bool ragged = b.slot_of || b.count_of;
     if (ragged && trace == 2) { dss_set_error("phase stamps are taken on uniform calls only"); return DSS_EINVAL; }
