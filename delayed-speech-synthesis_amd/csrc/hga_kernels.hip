@@ -5,15 +5,13 @@
 //   WarmStartFrameBuffer.insert                     extensions/hga/hga_optimized.pyx:96-131
 //   compute_log_power_features                      extensions/hga/hga_optimized.pyx:27-47
 //
-// Mapping: one lane per (stream, channel).  The path is a chain of 16 dependent biquads per sample and a
-// sequential 50-term sum per window, so time is the serial axis and channels x streams the parallel
-// one; consecutive lanes are consecutive channels, which makes every global access a coalesced
-// 8-byte-per-lane row segment of the (T, C) row-major layout the reference uses.
+// Three launches per call: (1) the IIR cascades with their sections spread over the 16 lanes of a DPP row (a column
+// advances one sample per step instead of one per 16 dependent biquads), (2) the windowed mean power with one lane per
+// (stream, window, channel) -- a 50-term sequential sum each, consecutive lanes = consecutive channels, so every access
+// is a coalesced row segment of the reference's (T, C) row-major layout -- and (3) the warm-start overlap copy.
 // Built with -ffp-contract=off: every product and sum rounds separately, as in scipy's C loop and in
 // the reference's Cython kernel, which is what makes the mean power bit-identical.
 #include "dss_common.h"
-
-#define HGA_CHUNK 8
 
 struct HgaSos { double k[2][8][6]; };
 
@@ -28,79 +26,117 @@ __device__ __forceinline__ int hga_win_stop(int start, float wl, int sr)
     return (int)round((double)(start + wl * sr));
 }
 
-// Filters n new rows of every (stream, channel) column, appends them to the column's row buffer at
-// row0, emits W window features from rows [0, rows) and keeps the last `overlap` rows for the next call.
-__global__ void __launch_bounds__(256)
-hga_extract_kernel(const double *__restrict__ data, double *__restrict__ zi, double *__restrict__ rowbuf,
-                   double *__restrict__ out, HgaSos sos, int S, int C, int n, int nsec, int row0, int rows, int W,
-                   int cap_rows, int overlap, int sr, float wl, float ws, int apply_log, int zero_rows)
+// ---- stage 1: the two IIR cascades, pipelined over their sections --------------------------------------------
+// The 2*nsec (<= 16) second-order sections of one (stream, channel) column occupy the 16 lanes of one DPP row: at
+// step k lane r filters sample k - r, taking its input from lane r-1's output of the previous step (row_shr:1), so
+// the column advances one sample per step instead of one per 16 biquads.  Each section's arithmetic is exactly
+// scipy's sosfilt inner loop (one product, one sum at a time).  A 256-thread block handles 16 consecutive columns
+// (same stream, consecutive channels), whose input samples are staged through LDS in tiles of HGA_TT rows with
+// 128-byte row segments; lane 2*nsec-1 writes the filtered sample to the column's row buffer at row0 + t.
+#define HGA_TT 64
+
+__device__ __forceinline__ double hga_row_shr1(double v)
 {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= S * C) return;
-    const int s = gid / C, c = gid - s * C;
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x111, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 
-    double z[2][8][2];
+__global__ void __launch_bounds__(256)
+hga_filter_kernel(const double *__restrict__ data, double *__restrict__ zi, double *__restrict__ rowbuf,
+                  HgaSos sos, int S, int C, int n, int nsec, int row0, int cap_rows, int zero_rows)
+{
+    __shared__ double xs[HGA_TT][16];
+    __shared__ double coef[16][5];
+    const int tid = threadIdx.x, r = tid & 15, pib = tid >> 4;
+    const long total = (long)S * C;
+    const long pair0 = (long)blockIdx.x * 16;
+    long pair = pair0 + pib;
+    const bool valid = pair < total;
+    if (!valid) pair = total - 1;
+    const int s = (int)(pair / C), c = (int)(pair - (long)s * C);
+    const int nsec2 = 2 * nsec;
+    const bool has_sec = r < nsec2;
+    const int f = has_sec ? r / nsec : 0, q = has_sec ? r - f * nsec : 0;
+    if (tid < 16) {           // section coefficients by lane (a kernel argument cannot be indexed per lane)
+        const int ff = tid < nsec2 ? tid / nsec : 0, qq = tid < nsec2 ? tid - ff * nsec : 0;
+        coef[tid][0] = sos.k[ff][qq][0]; coef[tid][1] = sos.k[ff][qq][1]; coef[tid][2] = sos.k[ff][qq][2];
+        coef[tid][3] = sos.k[ff][qq][4]; coef[tid][4] = sos.k[ff][qq][5];
+    }
     double *zp = zi + (size_t)s * 2 * 8 * 2 * C + c;
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            z[f][q][0] = zp[((f * 8 + q) * 2 + 0) * (size_t)C];
-            z[f][q][1] = zp[((f * 8 + q) * 2 + 1) * (size_t)C];
-        }
-
-    const double *x = data + (size_t)s * n * C + c;
+    double z0 = zp[((f * 8 + q) * 2 + 0) * (size_t)C], z1 = zp[((f * 8 + q) * 2 + 1) * (size_t)C];
     double *col = rowbuf + (size_t)s * cap_rows * C + c;
     // CASE 2 of the frame buffer (first chunk shorter than a frame): left zero padding, pyx:116
-    for (int r = 0; r < zero_rows; ++r) col[(size_t)r * C] = 0.0;
-
-    for (int t0 = 0; t0 < n; t0 += HGA_CHUNK) {
-        double v[HGA_CHUNK];
-#pragma unroll
-        for (int u = 0; u < HGA_CHUNK; ++u) v[u] = (t0 + u < n) ? x[(size_t)(t0 + u) * C] : 0.0;
-#pragma unroll
-        for (int u = 0; u < HGA_CHUNK; ++u) {
-            if (t0 + u < n) {
-                double cur = v[u];
-#pragma unroll
-                for (int f = 0; f < 2; ++f)
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (q < nsec) {
-                            const double b0 = sos.k[f][q][0], b1 = sos.k[f][q][1], b2 = sos.k[f][q][2];
-                            const double a1 = sos.k[f][q][4], a2 = sos.k[f][q][5];
-                            const double y = b0 * cur + z[f][q][0];
-                            z[f][q][0] = b1 * cur - a1 * y + z[f][q][1];
-                            z[f][q][1] = b2 * cur - a2 * y;
-                            cur = y;
-                        }
-                    }
-                col[(size_t)(row0 + t0 + u) * C] = cur;
+    if (valid)
+        for (int k = r; k < zero_rows; k += 16) col[(size_t)k * C] = 0.0;
+    __syncthreads();
+    const double b0 = coef[r][0], b1 = coef[r][1], b2 = coef[r][2], a1 = coef[r][3], a2 = coef[r][4];
+    const int steps = n + nsec2 - 1;
+    double y = 0.0;
+    for (int base = 0; base < steps; base += HGA_TT) {
+        __syncthreads();                                   // previous tile fully consumed
+        for (int idx = tid; idx < HGA_TT * 16; idx += 256) {
+            const int tt = idx >> 4, p = idx & 15;
+            const long pp = pair0 + p;
+            const int t = base + tt;
+            double v = 0.0;
+            if (t < n && pp < total) {
+                const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
+                v = data[((size_t)sp * n + t) * C + cp];
+            }
+            xs[tt][p] = v;
+        }
+        __syncthreads();
+        const int kend = min(base + HGA_TT, steps);
+        for (int k = base; k < kend; ++k) {
+            const double from_left = hga_row_shr1(y);      // all lanes take part in the shift
+            const double in = r == 0 ? xs[k - base][pib] : from_left;
+            const int t = k - r;
+            if (has_sec && t >= 0 && t < n) {
+                y = b0 * in + z0;                          // scipy _sosfilt: x_c = b0*x_n + zi0
+                z0 = b1 * in - a1 * y + z1;                //                 zi0 = b1*x_n - a1*x_c + zi1
+                z1 = b2 * in - a2 * y;                     //                 zi1 = b2*x_n - a2*x_c
+                if (r == nsec2 - 1 && valid) col[(size_t)(row0 + t) * C] = y;
             }
         }
     }
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            zp[((f * 8 + q) * 2 + 0) * (size_t)C] = z[f][q][0];
-            zp[((f * 8 + q) * 2 + 1) * (size_t)C] = z[f][q][1];
-        }
-
-    // windowed mean power over this lane's own column (only this lane ever wrote it)
-    double *o = out + (size_t)s * W * C + c;
-    for (int win = 0; win < W; ++win) {
-        const int start = hga_win_start(win, ws, sr);
-        const int stop = hga_win_stop(start, wl, sr);
-        double sum = 0.0;
-        for (int r = start; r < stop; ++r) {
-            const double q = col[(size_t)r * C];
-            sum += q * q;
-        }
-        double p = sum / (double)(stop - start) + 0.01;
-        o[(size_t)win * C] = apply_log ? log(p) : p;
+    if (valid && has_sec) {
+        zp[((f * 8 + q) * 2 + 0) * (size_t)C] = z0;
+        zp[((f * 8 + q) * 2 + 1) * (size_t)C] = z1;
     }
-    // keep the last `overlap` rows (ascending copy: source row is always ahead of destination row)
+}
+
+// ---- stage 2: windowed mean power, one lane per (stream, window, channel) -----------------------------------------
+__global__ void __launch_bounds__(256)
+hga_window_kernel(const double *__restrict__ rowbuf, double *__restrict__ out, int S, int C, int W, int cap_rows, int sr,
+                  float wl, float ws, int apply_log)
+{
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)S * W * C) return;
+    const int c = (int)(gid % C);
+    const int win = (int)((gid / C) % W);
+    const int s = (int)(gid / ((long)C * W));
+    const double *col = rowbuf + (size_t)s * cap_rows * C + c;
+    const int start = hga_win_start(win, ws, sr);
+    const int stop = hga_win_stop(start, wl, sr);
+    double sum = 0.0;
+    for (int rr = start; rr < stop; ++rr) {                // array_sum_and_power, pyx:9-22: sequential over rows
+        const double v = col[(size_t)rr * C];
+        sum += v * v;
+    }
+    const double p = sum / (double)(stop - start) + 0.01;
+    out[gid] = apply_log ? log(p) : p;
+}
+
+// ---- stage 3: keep the last `overlap` rows (ascending copy: a source row is always ahead of its destination) ------
+__global__ void __launch_bounds__(256)
+hga_overlap_kernel(double *__restrict__ rowbuf, int S, int C, int cap_rows, int rows, int overlap)
+{
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)S * C) return;
+    const int s = (int)(gid / C), c = (int)(gid - (long)s * C);
+    double *col = rowbuf + (size_t)s * cap_rows * C + c;
     for (int k = 0; k < overlap; ++k) col[(size_t)k * C] = col[(size_t)(rows - overlap + k) * C];
 }
 
@@ -109,11 +145,18 @@ int dss_launch_hga(const DssHgaDev &h, const double *d_data, int n, int row0, in
 {
     HgaSos sos;
     memcpy(&sos, h.sos, sizeof(sos));
-    const int total = h.S * h.C;
-    const int block = 64;                      // small blocks: few lanes, long serial chains -> spread over CUs
-    const int grid = (total + block - 1) / block;
-    hipLaunchKernelGGL(hga_extract_kernel, dim3(grid), dim3(block), 0, st, d_data, h.zi, h.rows, d_out, sos, h.S, h.C, n,
-                       h.nsec, row0, rows, W, h.cap_rows, h.overlap, h.fs, h.wl, h.ws, apply_log, zero_rows);
+    const long pairs = (long)h.S * h.C;
+    hipLaunchKernelGGL(hga_filter_kernel, dim3((unsigned)((pairs + 15) / 16)), dim3(256), 0, st, d_data, h.zi, h.rows, sos,
+                       h.S, h.C, n, h.nsec, row0, h.cap_rows, zero_rows);
+    DSS_HIP_CHECK(hipGetLastError());
+    if (W > 0) {
+        const long total = pairs * W;
+        hipLaunchKernelGGL(hga_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h.rows, d_out, h.S,
+                           h.C, W, h.cap_rows, h.fs, h.wl, h.ws, apply_log);
+        DSS_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(hga_overlap_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, h.rows, h.S, h.C,
+                       h.cap_rows, rows, h.overlap);
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }
