@@ -35,20 +35,31 @@ __device__ __forceinline__ int hga_win_stop(int start, float wl, int sr)
 // 128-byte row segments; lane 2*nsec-1 writes the filtered sample to the column's row buffer at row0 + t.
 #define HGA_TT 64
 
-__device__ __forceinline__ double hga_row_shr1(double v)
+// lanes 1..15 of every row receive their left neighbour's `y`; lane 0 (no neighbour) keeps `x`: the column's input
+__device__ __forceinline__ double hga_shift_in(double x, double y)
 {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x111, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x111, 0xf, 0xf, false);
+    const unsigned long long ux = __builtin_bit_cast(unsigned long long, x), uy = __builtin_bit_cast(unsigned long long, y);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)ux, (int)(unsigned)uy, 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(ux >> 32), (int)(unsigned)(uy >> 32), 0x111, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
+
+// one step of one section: scipy _sosfilt's inner statement order
+#define HGA_BIQUAD(IN)                                                                           \
+    {                                                                                            \
+        y = b0 * (IN) + z0;                        /* x_c = b0*x_n + zi0        */               \
+        z0 = b1 * (IN) - a1 * y + z1;              /* zi0 = b1*x_n - a1*x_c + zi1 */             \
+        z1 = b2 * (IN) - a2 * y;                   /* zi1 = b2*x_n - a2*x_c     */               \
+    }
 
 __global__ void __launch_bounds__(256)
 hga_filter_kernel(const double *__restrict__ data, double *__restrict__ zi, double *__restrict__ rowbuf,
                   HgaSos sos, int S, int C, int n, int nsec, int row0, int cap_rows, int zero_rows)
 {
-    __shared__ double xs[HGA_TT][16];
+    __shared__ double xs[HGA_TT + 1][16];      // inputs of the tile's steps, one row segment of 16 columns per step (+1: prefetch)
+    __shared__ double ys[HGA_TT][16];          // outputs produced at the tile's steps (sample k - (2*nsec-1) at step k)
     __shared__ double coef[16][5];
+    __shared__ double dump[256];               // where the lanes that do not hold the last section "store" their y
     const int tid = threadIdx.x, r = tid & 15, pib = tid >> 4;
     const long total = (long)S * C;
     const long pair0 = (long)blockIdx.x * 16;
@@ -58,6 +69,11 @@ hga_filter_kernel(const double *__restrict__ data, double *__restrict__ zi, doub
     const int s = (int)(pair / C), c = (int)(pair - (long)s * C);
     const int nsec2 = 2 * nsec;
     const bool has_sec = r < nsec2;
+    const bool is_last = r == nsec2 - 1;
+    // branch-free output store of the steady-state loop: the last section's lane walks down its ys column, every other
+    // lane rewrites its own dump word
+    char *const ybase = is_last ? reinterpret_cast<char *>(&ys[0][pib]) : reinterpret_cast<char *>(&dump[tid]);
+    const int ystride = is_last ? 16 * (int)sizeof(double) : 0;
     const int f = has_sec ? r / nsec : 0, q = has_sec ? r - f * nsec : 0;
     if (tid < 16) {           // section coefficients by lane (a kernel argument cannot be indexed per lane)
         const int ff = tid < nsec2 ? tid / nsec : 0, qq = tid < nsec2 ? tid - ff * nsec : 0;
@@ -66,16 +82,17 @@ hga_filter_kernel(const double *__restrict__ data, double *__restrict__ zi, doub
     }
     double *zp = zi + (size_t)s * 2 * 8 * 2 * C + c;
     double z0 = zp[((f * 8 + q) * 2 + 0) * (size_t)C], z1 = zp[((f * 8 + q) * 2 + 1) * (size_t)C];
-    double *col = rowbuf + (size_t)s * cap_rows * C + c;
     // CASE 2 of the frame buffer (first chunk shorter than a frame): left zero padding, pyx:116
-    if (valid)
+    if (valid) {
+        double *col = rowbuf + (size_t)s * cap_rows * C + c;
         for (int k = r; k < zero_rows; k += 16) col[(size_t)k * C] = 0.0;
+    }
     __syncthreads();
     const double b0 = coef[r][0], b1 = coef[r][1], b2 = coef[r][2], a1 = coef[r][3], a2 = coef[r][4];
     const int steps = n + nsec2 - 1;
     double y = 0.0;
     for (int base = 0; base < steps; base += HGA_TT) {
-        __syncthreads();                                   // previous tile fully consumed
+        __syncthreads();                                   // previous tile fully consumed and written out
         for (int idx = tid; idx < HGA_TT * 16; idx += 256) {
             const int tt = idx >> 4, p = idx & 15;
             const long pp = pair0 + p;
@@ -89,15 +106,49 @@ hga_filter_kernel(const double *__restrict__ data, double *__restrict__ zi, doub
         }
         __syncthreads();
         const int kend = min(base + HGA_TT, steps);
-        for (int k = base; k < kend; ++k) {
-            const double from_left = hga_row_shr1(y);      // all lanes take part in the shift
-            const double in = r == 0 ? xs[k - base][pib] : from_left;
+        int k = base;
+        // steps on which some lanes have no sample yet (pipeline filling) or no more (draining): predicated
+        for (; k < kend && (k < nsec2 - 1 || k >= n); ++k) {
+            const double in = hga_shift_in(xs[k - base][pib], y);
             const int t = k - r;
             if (has_sec && t >= 0 && t < n) {
-                y = b0 * in + z0;                          // scipy _sosfilt: x_c = b0*x_n + zi0
-                z0 = b1 * in - a1 * y + z1;                //                 zi0 = b1*x_n - a1*x_c + zi1
-                z1 = b2 * in - a2 * y;                     //                 zi1 = b2*x_n - a2*x_c
-                if (r == nsec2 - 1 && valid) col[(size_t)(row0 + t) * C] = y;
+                HGA_BIQUAD(in)
+                if (is_last) ys[k - base][pib] = y;
+            }
+        }
+        // steady state: every section has a sample
+        const int ksteady = min(kend, n);
+        {
+            char *yp = ybase + (k - base) * ystride;
+            const double *xp = &xs[k - base][pib];
+            double xcur = *xp;
+            for (; k < ksteady; ++k) {
+                xp += 16;
+                const double xnext = *xp;                  // next step's input: its LDS latency hides under this step
+                const double in = hga_shift_in(xcur, y);
+                HGA_BIQUAD(in)
+                *reinterpret_cast<double *>(yp) = y;
+                yp += ystride;
+                xcur = xnext;
+            }
+        }
+        for (; k < kend; ++k) {                            // draining steps at the end of the last tile(s)
+            const double in = hga_shift_in(xs[k - base][pib], y);
+            const int t = k - r;
+            if (has_sec && t >= 0 && t < n) {
+                HGA_BIQUAD(in)
+                if (is_last) ys[k - base][pib] = y;
+            }
+        }
+        __syncthreads();
+        // the tile's finished samples go out as 128-byte row segments
+        for (int idx = tid; idx < HGA_TT * 16; idx += 256) {
+            const int tt = idx >> 4, p = idx & 15;
+            const long pp = pair0 + p;
+            const int t = base + tt - (nsec2 - 1);
+            if (base + tt < kend && t >= 0 && t < n && pp < total) {
+                const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
+                rowbuf[((size_t)sp * cap_rows + row0 + t) * C + cp] = ys[tt][p];
             }
         }
     }
