@@ -574,14 +574,24 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 const unsigned long long m1 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.z);
                 const unsigned long long m2 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.x);
                 const unsigned long long m3 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.z);
-                int val = 0;
-#pragma unroll
-                for (int lv = 0; lv < 6; ++lv) {                                        // nodes 1..63 live in m0
-                    const int node = (1 << lv) | val;
-                    val = (val << 1) | (int)((m0 >> node) & 1);
-                }
-                { const int node = 64 | val; val = (val << 1) | (int)((m1 >> (node - 64)) & 1); }
-                { const int node = 128 | val; const unsigned long long mm = node < 192 ? m2 : m3; val = (val << 1) | (int)((mm >> (node & 63)) & 1); }
+                // 8 levels, 3 scalar instructions each: test the node's bit (s_bitcmp1_b64 -> SCC), val = 2*val + SCC
+                // (s_addc_u32), next node index.  Nodes 1..63 live in m0, 64..127 in m1, 128..191 in m2, 192..255 in m3.
+                int val, tnode;
+                unsigned long long mm;
+                asm volatile(
+                    "s_mov_b32 %0, 0\n\t"
+                    "s_bitcmp1_b64 %3, 1\n\t"          "s_addc_u32 %0, %0, %0\n\t"
+                    "s_or_b32 %1, %0, 2\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
+                    "s_or_b32 %1, %0, 4\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
+                    "s_or_b32 %1, %0, 8\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
+                    "s_or_b32 %1, %0, 16\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
+                    "s_or_b32 %1, %0, 32\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
+                    "s_bitcmp1_b64 %4, %0\n\t"         "s_addc_u32 %0, %0, %0\n\t"
+                    "s_cmp_lt_u32 %0, 64\n\t"          "s_cselect_b64 %2, %5, %6\n\t"
+                    "s_bitcmp1_b64 %2, %0\n\t"         "s_addc_u32 %0, %0, %0"
+                    : "=&s"(val), "=&s"(tnode), "=&s"(mm)
+                    : "s"(m0), "s"(m1), "s"(m2), "s"(m3)
+                    : "scc");
                 const int exc = val;
                 // the next sample's prediction and mu-law indices were precomputed for every possible exc
                 const unsigned sidx = L.spec_tab_idx[exc];
