@@ -159,6 +159,11 @@ struct SampleLds {
     {                                                                                            \
         f32x4 avA[4], avB[4];                                                                    \
         DSS_GB_LOAD(avA, AN, 0)                                                                  \
+        DSS_GB_CHAIN_RUN(AN, N)                                                                  \
+    }
+// the same with the first group's reads already issued by the caller (avA, avB declared there)
+#define DSS_GB_CHAIN_RUN(AN, N)                                                                  \
+    {                                                                                            \
         _Pragma("unroll") for (int g = 0; g < (N) / 16; g += 2) {                                \
             if (g + 1 < (N) / 16) DSS_GB_LOAD(avB, AN, g + 1)                                    \
             __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch ahead of the arithmetic */ \
@@ -524,12 +529,15 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 for (int j = 0; j < NB; ++j) rec += L.gb_wrec[j * NB3 + row] * L.state_b[j];
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[2] += t - t_prev; t_prev = t; }
+                const float *an = L.state_a[cur ^ 1] + GBH6;
+                f32x4 avA[4], avB[4];
+                DSS_GB_LOAD(avA, an, 0)                      // the new GRU A state is there since barrier B
+                __builtin_amdgcn_sched_barrier(0);
                 while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
                     __builtin_amdgcn_s_sleep(1);
                 float acc = L.gb_acc[lane];
                 {
-                    const float *an = L.state_a[cur ^ 1] + GBH6;
-                    DSS_GB_CHAIN(an, GBH7)
+                    DSS_GB_CHAIN_RUN(an, GBH7)
                     const float *al = an + GBH7, *wl = L.gb_wl + row * GBL_STRIDE;
                     f32x4 tA[4], tB[4];                   // [0..1] state, [2..3] weights of two groups of 4 inputs
                     DSS_GBL_LOAD(tA, 0)
@@ -551,15 +559,20 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                {   // gates: lanes 0..15 z, 16..31 r, 32..47 h
+                {   // gates: lanes 0..15 z, 16..31 r, 32..47 h.  r and z travel up to their unit's h lane with gfx950's
+                    // row/half swaps (VALU) instead of ds_bpermute (an LDS round trip each, on the sample's critical
+                    // path); the new state is formed in the h lanes.  Only the first result of a swap is used, with
+                    // distinct operands: the second one came back wrong from this compiler.
                     const float zr = dss_sigmoid_approx(L.tansig, acc + rec);
-                    const float r_for_h = __shfl(zr, lane - NB);                      // r_i for lane 32+i
+                    const unsigned zb = __builtin_bit_cast(unsigned, zr);
+                    const unsigned r_row0 = __builtin_amdgcn_permlane16_swap(zb, 0u, false, false)[1];                  // lanes 0..15 <- 16..31
+                    const float r_for_h = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(0u, r_row0, false, false)[0]);  // 32..47 <- 0..15
+                    const float z_for_h = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(0u, zb, false, false)[0]);      // 32..47 <- 0..15
                     float hh = acc + rec * r_for_h;
                     hh = dss_tanh_approx(L.tansig, hh);
-                    const float h_for_z = __shfl(hh, lane + 2 * NB);                  // h_i for lane i
-                    if (lane < NB) {
-                        const float sb = L.state_b[lane];
-                        L.state_b[lane] = zr * sb + (1 - zr) * h_for_z;
+                    if (lane >= 2 * NB && lane < NB3) {
+                        const float sb = L.state_b[lane - 2 * NB];
+                        L.state_b[lane - 2 * NB] = z_for_h * sb + (1 - z_for_h) * hh;
                     }
                 }
                 __syncthreads();                                                        // barrier C
