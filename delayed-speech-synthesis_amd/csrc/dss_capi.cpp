@@ -306,12 +306,12 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         // Two independent lane assignments, both "8 row groups per wave":
         //  * h-gate chains (LDS resident): groups sorted by h block count, so each wave's loop length (its
         //    largest group) is close to what all its groups need and the LDS image stays small;
-        //  * z/r chains (register resident): groups sorted by max(z, r) block count.
-        // Both the h chain and the z/r block products run between barriers B and C, under the GRU B relay.
-        // The z/r ranking is dealt in the opposite order of the h ranking, so every wave's total (h chain + z/r
-        // products) is about the same; waves 2 and 3, which share their SIMD with the two high-priority relay
-        // waves, get the lightest h chains and therefore the heaviest z/r chunks -- whose sums they then run
-        // between barriers A and B, when they have their SIMD to themselves.
+        //  * z/r chains (register resident): groups sorted by max(z, r) block count.  The 16 heaviest groups go to
+        //    waves 4 and 5, whose code path carries no dual-FC weights and therefore has room for all DSS_ZRC register
+        //    slots per gate; waves 0..3 run the 8-slot instantiation, so the other 32 groups must fit 8 slots.
+        // Both the h chain and the z/r block products run between barriers B and C, under the GRU B relay; waves 4
+        // and 5 also run the speculation there, so they get the lightest h chains, and among waves 0..3 the heavier
+        // z/r groups go with the lighter h chains.
         // The per-unit pre-activation of the h gate travels from its h lane to its z/r lane through LDS.
         std::vector<int> order_h(G), order_zr(G);
         for (int g = 0; g < G; ++g) order_h[g] = order_zr[g] = g;
@@ -320,7 +320,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
             return std::max(cnt[a], cnt[G + a]) > std::max(cnt[b2], cnt[G + b2]);
         });
         static const int rank_wave_h[6] = {0, 1, 3, 2, 5, 4};
-        static const int rank_wave_zr[6] = {3, 2, 5, 4, 1, 0};
+        static const int rank_wave_zr[6] = {4, 5, 2, 3, 1, 0};
         std::vector<int> unit_of(NA, 0), unit_h(NA, 0), wave_nh(8, 0), wave_hoff(8, 0), wave_nzr(8, 0), grp_h(G, 0), grp_zr(G, 0);
         int hfloats = 0;
         for (int rk = 0; rk < 6 && fast_ok; ++rk) {
@@ -333,6 +333,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
             }
             wave_nh[rank_wave_h[rk]] = (nh + 1) & ~1;       // the kernel tests for the end of a list every 2 slots
             wave_nzr[rank_wave_zr[rk]] = (nzr + 1) & ~1;
+            if (rank_wave_zr[rk] < 4 && nzr > 8) fast_ok = 0;     // waves 0..3: 8 register slots per gate
         }
         for (int wv = 0; wv < 6 && fast_ok; ++wv) {
             wave_hoff[wv] = hfloats;

@@ -220,6 +220,174 @@ struct SampleLds {
         upd_pending = false;                                                                     \
     }
 
+// =====================================================================================================
+// role A: GRU A (+ dual-FC on waves 0..3, + the speculation on waves 4..5).  Two instantiations share this text:
+//   waves 0..3  HAS_FC, at most 8 z/r register slots per gate (the dual-FC weights take 32 registers);
+//   waves 4..5  no dual-FC, all Z slots -- the host gives them the row groups with the most z/r blocks.
+// Keeping the two apart is what keeps either under the 256-VGPR budget without spill reloads in the sample loop.
+// =====================================================================================================
+template <bool TRACE, bool STAMP, int Z, bool HAS_FC>
+__device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const DssModelDev &m, const DssBatchDev &b,
+                                           int n_frames, int utt, int slot, int nf, int fc0, int tid, int wave, int lane)
+{
+    const int unit = m.unit_of[tid];                             // z/r chains + gates of this unit
+    const int uh = m.unit_h[tid];                                // h-gate chain of this (other) unit
+    const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
+    const int nzr = __builtin_amdgcn_readfirstlane(m.wave_nzr[wave]);
+    const char *hw = reinterpret_cast<const char *>(hblk_lds + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
+                     ((lane >> 3) * (nh + 1) * 128 + (lane & 7) * 16);
+    f32x4 WZ[2 * ZRC];                                           // [0,ZRC) z slots, [ZRC,2ZRC) r slots
+    unsigned PZ[(2 * ZRL + 3) / 4], PH[HC / 4];
+#pragma unroll
+    for (int s = 0; s < 2 * ZRC; ++s) {
+        const int slot = s < ZRC ? s : ZRL + (s - ZRC);          // layout numbering
+        WZ[s].x = m.zr_w[((size_t)slot * 4 + 0) * NA + tid];
+        WZ[s].y = m.zr_w[((size_t)slot * 4 + 1) * NA + tid];
+        WZ[s].z = m.zr_w[((size_t)slot * 4 + 2) * NA + tid];
+        WZ[s].w = m.zr_w[((size_t)slot * 4 + 3) * NA + tid];
+    }
+#pragma unroll
+    for (int s = 0; s < (2 * ZRL + 3) / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
+#pragma unroll
+    for (int s = 0; s < HC / 4; ++s) PH[s] = m.h_col[(size_t)s * NA + tid];
+    const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + uh];
+    const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + uh];
+    // dual-FC constants of tree node `tid` (waves 0..3)
+    f32x4 fw[HAS_FC ? 2 * NB / 4 : 1];
+    float fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
+    if constexpr (HAS_FC) {
+        const int node = tid;
+#pragma unroll
+        for (int k = 0; k < 2 * NB / 4; ++k) fw[k] = *reinterpret_cast<const f32x4 *>(m.fc_w + (size_t)node * 2 * NB + 4 * k);
+        fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
+        ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
+    }
+    const int cand = tid & 127;                                  // waves 4, 5: excitation candidates cand, cand+128
+    const float u2l_a = L.ulaw2lin[cand], u2l_b = L.ulaw2lin[cand + 128];
+    const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
+    int cur = 0;
+    float st = L.state_a[0][unit];
+    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
+    f32x4 PR[2 * ZRC];                                           // z/r block products of the coming sample
+    DSS_H_CHAIN(L.state_a[0])                                    // first sample of this call
+    DSS_ZR_PRODUCTS(L.state_a[0])
+    __syncthreads();                                             // L.ah of every unit visible to its z/r lane
+
+    for (int f = 0; f < nf; ++f) {
+        if (fc0 + f < DSS_FEATURES_DELAY) continue;              // silent frame: decoder state untouched
+        const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;     // wave-uniform base
+        const float cz = fo[(unsigned)unit], cr = fo[(unsigned)(NA + unit)], ch = fo[(unsigned)(2 * NA + unit)];
+        for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+            // keep the packed column ids opaque so the per-slot unpacking is not hoisted out of the sample
+            // loop into (spilled) registers
+#pragma unroll
+            for (int k = 0; k < (2 * ZRL + 3) / 4; ++k) asm volatile("" : "+v"(PZ[k]));
+#pragma unroll
+            for (int k = 0; k < HC / 4; ++k) asm volatile("" : "+v"(PH[k]));
+            float az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
+            float ar = rbr + dgr * st;
+            const float ahv = L.ah[unit];                        // this unit's h-gate pre-activation (its h lane, B..C)
+            __syncthreads();                                                        // barrier A
+            if (STAMP) ta = __builtin_readcyclecounter();
+            {
+                const int si = L.idx[0], pi = L.idx[1], ei = L.idx[2];
+                // 32-bit element offsets from the (scalar) table bases: no 64-bit per-lane pointers to keep alive
+                const unsigned so = (unsigned)si * (3 * NA) + (unsigned)unit;
+                const unsigned po = (unsigned)pi * (3 * NA) + (unsigned)unit;
+                const unsigned eo = (unsigned)ei * (3 * NA) + (unsigned)unit;
+                // the nine embedding values of this lane
+                const float es0 = m.embed_sig[so], es1 = m.embed_sig[so + NA], es2 = m.embed_sig[so + 2 * NA];
+                const float ep0 = m.embed_pred[po], ep1 = m.embed_pred[po + NA], ep2 = m.embed_pred[po + 2 * NA];
+                const float ee0 = m.embed_exc[eo], ee1 = m.embed_exc[eo + NA], ee2 = m.embed_exc[eo + 2 * NA];
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[0] += t - ta; ta = t; }
+                const float gz = ((cz + es0) + ep0) + ee0;                          // compute_gru_a_input
+                const float gr = ((cr + es1) + ep1) + ee1;
+                const float gh = ((ch + es2) + ep2) + ee2;
+                az = az + gz;                       // (bias + diag*state) + input, then the blocks in idx order
+                ar = ar + gr;
+                if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[1] += t - ta; ta = t; }
+                // the block products were formed right after the previous sample's state update (under GRU B);
+                // what is left on the critical path are the dependent sums, z and r chains interleaved
+#pragma unroll
+                for (int s2 = 0; s2 < ZRC; s2 += 2) {
+                    if (s2 >= nzr) break;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        az += PR[s2 + u].x; ar += PR[ZRC + s2 + u].x;
+                        az += PR[s2 + u].y; ar += PR[ZRC + s2 + u].y;
+                        az += PR[s2 + u].z; ar += PR[ZRC + s2 + u].z;
+                        az += PR[s2 + u].w; ar += PR[ZRC + s2 + u].w;
+                    }
+                }
+                if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
+                float z, r;
+                dss_sigmoid_approx2(L.tansig, az, ar, z, r);
+                float h = ahv * r + gh;
+                h = dss_tanh_approx(L.tansig, h);
+                st = z * st + (1 - z) * h;
+                L.state_a[cur ^ 1][unit] = st;
+                if (STAMP) { asm volatile("" :: "v"(st)); unsigned long long t = __builtin_readcyclecounter(); sa[3] += t - ta; ta = t; }
+            }
+            __syncthreads();                                                        // barrier B
+            if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
+            DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
+            DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
+            if constexpr (!HAS_FC) {
+                // Speculation over all 256 possible excitation values of THIS sample (waves 4 and 5, two
+                // candidates per lane): the next sample's LPC prediction and mu-law indices, so that once the
+                // tree walk has picked the value, wave 7 only looks the result up instead of running two
+                // ~40-step dependent chains.  Same expressions, same order as lpcnet_synthesize_tail_impl().
+                const float sp = L.spec_pred;
+                const float pcm_a = sp + u2l_a, pcm_b = sp + u2l_b;
+                const float l0 = L.spec_lpc[0];
+                float pa = 0, pb = 0;
+                pa -= pcm_a * l0; pb -= pcm_b * l0;
+#pragma unroll
+                for (int j = 1; j < DSS_LPC_ORDER; ++j) {
+                    const float t2 = L.spec_ls[j - 1] * L.spec_lpc[j];          // same product for every candidate
+                    pa -= t2; pb -= t2;
+                }
+                const int su_a = dss_lin2ulaw(pcm_a), su_b = dss_lin2ulaw(pcm_b);
+                const int pu_a = dss_lin2ulaw(pa), pu_b = dss_lin2ulaw(pb);
+                L.spec_tab_pred[cand] = pa; L.spec_tab_pred[cand + 128] = pb;
+                L.spec_tab_idx[cand] = (unsigned short)(su_a | (pu_a << 8));
+                L.spec_tab_idx[cand + 128] = (unsigned short)(su_b | (pu_b << 8));
+            }
+            if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
+            __syncthreads();                                                        // barrier C
+            if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
+            if constexpr (HAS_FC) {                                                 // sample_mdense, all nodes
+                const float thr_lv = L.thr[level];                                  // issued first, used last
+                float s1 = fb0, s2 = fb1;
+#pragma unroll
+                for (int j4 = 0; j4 < NB / 4; ++j4) {
+                    const f32x4 bj = *reinterpret_cast<const f32x4 *>(L.state_b + 4 * j4);
+                    const f32x4 w0 = fw[j4], w1 = fw[NB / 4 + j4];
+                    s1 += w0.x * bj.x; s2 += w1.x * bj.x;
+                    s1 += w0.y * bj.y; s2 += w1.y * bj.y;
+                    s1 += w0.z * bj.z; s2 += w1.z * bj.z;
+                    s1 += w0.w * bj.w; s2 += w1.w * bj.w;
+                }
+                float t1, t2;
+                dss_tanh_approx2(L.tansig, s1, s2, t1, t2);
+                s1 = ff0 * t1;
+                s2 = ff1 * t2;
+                s1 += s2;
+                const bool bit = thr_lv < s1;
+                const unsigned long long mask = __ballot(bit);
+                if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
+            }
+            __syncthreads();                                                        // barrier D
+            if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[7] += t - ta; ta = t; }
+            cur ^= 1;
+        }
+    }
+    __syncthreads();                                                                // final barrier
+    if (STAMP && lane == 0 && b.trace_exc)
+        for (int k = 0; k < 8; ++k) b.trace_exc[((size_t)utt * 6 + wave) * 8 + k] = (float)sa[k];
+    b.gru_a_state[(size_t)slot * NA + unit] = st;
+}
+
 // RAGGED: rows name their decoder slot and frame count (b.slot_of / b.count_of).  A separate instantiation, so the
 // uniform form keeps its register allocation (the two extra live scalars cost 1.3 % there); the trace build always
 // honours the lists.
@@ -254,166 +422,10 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     const int fc0 = b.fc0[utt];
     __syncthreads();
 
-    if (wave < 6) {
-        // =====================================================================================================
-        // role A: GRU A (+ dual-FC on waves 0..3)
-        // =====================================================================================================
-        const int unit = m.unit_of[tid];                             // z/r chains + gates of this unit
-        const int uh = m.unit_h[tid];                                // h-gate chain of this (other) unit
-        const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
-        const int nzr = __builtin_amdgcn_readfirstlane(m.wave_nzr[wave]);
-        const char *hw = reinterpret_cast<const char *>(hblk_lds + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
-                         ((lane >> 3) * (nh + 1) * 128 + (lane & 7) * 16);
-        f32x4 WZ[2 * ZRC];                                           // [0,ZRC) z slots, [ZRC,2ZRC) r slots
-        unsigned PZ[(2 * ZRL + 3) / 4], PH[HC / 4];
-#pragma unroll
-        for (int s = 0; s < 2 * ZRC; ++s) {
-            const int slot = s < ZRC ? s : ZRL + (s - ZRC);          // layout numbering
-            WZ[s].x = m.zr_w[((size_t)slot * 4 + 0) * NA + tid];
-            WZ[s].y = m.zr_w[((size_t)slot * 4 + 1) * NA + tid];
-            WZ[s].z = m.zr_w[((size_t)slot * 4 + 2) * NA + tid];
-            WZ[s].w = m.zr_w[((size_t)slot * 4 + 3) * NA + tid];
-        }
-#pragma unroll
-        for (int s = 0; s < (2 * ZRL + 3) / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
-#pragma unroll
-        for (int s = 0; s < HC / 4; ++s) PH[s] = m.h_col[(size_t)s * NA + tid];
-        const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + uh];
-        const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + uh];
-        // dual-FC constants of tree node `tid` (waves 0..3)
-        f32x4 fw[2 * NB / 4];
-        float fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
-        {
-            const int node = tid < DSS_FC_OUT ? tid : 0;
-#pragma unroll
-            for (int k = 0; k < 2 * NB / 4; ++k) fw[k] = *reinterpret_cast<const f32x4 *>(m.fc_w + (size_t)node * 2 * NB + 4 * k);
-            fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
-            ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
-        }
-        const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
-        const int cand = tid & 127;                                  // waves 4, 5: excitation candidates cand, cand+128
-        const float u2l_a = L.ulaw2lin[cand], u2l_b = L.ulaw2lin[cand + 128];
-        int cur = 0;
-        float st = L.state_a[0][unit];
-        unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
-        f32x4 PR[2 * ZRC];                                           // z/r block products of the coming sample
-        DSS_H_CHAIN(L.state_a[0])                                    // first sample of this call
-        DSS_ZR_PRODUCTS(L.state_a[0])
-        __syncthreads();                                             // L.ah of every unit visible to its z/r lane
-
-        for (int f = 0; f < nf; ++f) {
-            if (fc0 + f < DSS_FEATURES_DELAY) continue;              // silent frame: decoder state untouched
-            const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;     // wave-uniform base
-            const float cz = fo[(unsigned)unit], cr = fo[(unsigned)(NA + unit)], ch = fo[(unsigned)(2 * NA + unit)];
-            for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
-                // keep the packed column ids opaque so the per-slot unpacking is not hoisted out of the sample
-                // loop into (spilled) registers
-#pragma unroll
-                for (int k = 0; k < (2 * ZRL + 3) / 4; ++k) asm volatile("" : "+v"(PZ[k]));
-#pragma unroll
-                for (int k = 0; k < HC / 4; ++k) asm volatile("" : "+v"(PH[k]));
-                float az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
-                float ar = rbr + dgr * st;
-                const float ahv = L.ah[unit];                        // this unit's h-gate pre-activation (its h lane, B..C)
-                __syncthreads();                                                        // barrier A
-                if (STAMP) ta = __builtin_readcyclecounter();
-                {
-                    const int si = L.idx[0], pi = L.idx[1], ei = L.idx[2];
-                    // 32-bit element offsets from the (scalar) table bases: no 64-bit per-lane pointers to keep alive
-                    const unsigned so = (unsigned)si * (3 * NA) + (unsigned)unit;
-                    const unsigned po = (unsigned)pi * (3 * NA) + (unsigned)unit;
-                    const unsigned eo = (unsigned)ei * (3 * NA) + (unsigned)unit;
-                    // the nine embedding values of this lane
-                    const float es0 = m.embed_sig[so], es1 = m.embed_sig[so + NA], es2 = m.embed_sig[so + 2 * NA];
-                    const float ep0 = m.embed_pred[po], ep1 = m.embed_pred[po + NA], ep2 = m.embed_pred[po + 2 * NA];
-                    const float ee0 = m.embed_exc[eo], ee1 = m.embed_exc[eo + NA], ee2 = m.embed_exc[eo + 2 * NA];
-                    if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[0] += t - ta; ta = t; }
-                    const float gz = ((cz + es0) + ep0) + ee0;                          // compute_gru_a_input
-                    const float gr = ((cr + es1) + ep1) + ee1;
-                    const float gh = ((ch + es2) + ep2) + ee2;
-                    az = az + gz;                       // (bias + diag*state) + input, then the blocks in idx order
-                    ar = ar + gr;
-                    if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[1] += t - ta; ta = t; }
-                    // the block products were formed right after the previous sample's state update (under GRU B);
-                    // what is left on the critical path are the dependent sums, z and r chains interleaved
-#pragma unroll
-                    for (int s2 = 0; s2 < ZRC; s2 += 2) {
-                        if (s2 >= nzr) break;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            az += PR[s2 + u].x; ar += PR[ZRC + s2 + u].x;
-                            az += PR[s2 + u].y; ar += PR[ZRC + s2 + u].y;
-                            az += PR[s2 + u].z; ar += PR[ZRC + s2 + u].z;
-                            az += PR[s2 + u].w; ar += PR[ZRC + s2 + u].w;
-                        }
-                    }
-                    if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
-                    float z, r;
-                    dss_sigmoid_approx2(L.tansig, az, ar, z, r);
-                    float h = ahv * r + gh;
-                    h = dss_tanh_approx(L.tansig, h);
-                    st = z * st + (1 - z) * h;
-                    L.state_a[cur ^ 1][unit] = st;
-                    if (STAMP) { asm volatile("" :: "v"(st)); unsigned long long t = __builtin_readcyclecounter(); sa[3] += t - ta; ta = t; }
-                }
-                __syncthreads();                                                        // barrier B
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
-                DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
-                DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
-                if (wave >= 4) {
-                    // Speculation over all 256 possible excitation values of THIS sample (waves 4 and 5, two
-                    // candidates per lane): the next sample's LPC prediction and mu-law indices, so that once the
-                    // tree walk has picked the value, wave 7 only looks the result up instead of running two
-                    // ~40-step dependent chains.  Same expressions, same order as lpcnet_synthesize_tail_impl().
-                    const float sp = L.spec_pred;
-                    const float pcm_a = sp + u2l_a, pcm_b = sp + u2l_b;
-                    const float l0 = L.spec_lpc[0];
-                    float pa = 0, pb = 0;
-                    pa -= pcm_a * l0; pb -= pcm_b * l0;
-#pragma unroll
-                    for (int j = 1; j < DSS_LPC_ORDER; ++j) {
-                        const float t2 = L.spec_ls[j - 1] * L.spec_lpc[j];          // same product for every candidate
-                        pa -= t2; pb -= t2;
-                    }
-                    const int su_a = dss_lin2ulaw(pcm_a), su_b = dss_lin2ulaw(pcm_b);
-                    const int pu_a = dss_lin2ulaw(pa), pu_b = dss_lin2ulaw(pb);
-                    L.spec_tab_pred[cand] = pa; L.spec_tab_pred[cand + 128] = pb;
-                    L.spec_tab_idx[cand] = (unsigned short)(su_a | (pu_a << 8));
-                    L.spec_tab_idx[cand + 128] = (unsigned short)(su_b | (pu_b << 8));
-                }
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
-                __syncthreads();                                                        // barrier C
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
-                if (tid < DSS_FC_OUT) {                                                 // sample_mdense, all nodes
-                    const float thr_lv = L.thr[level];                                  // issued first, used last
-                    float s1 = fb0, s2 = fb1;
-#pragma unroll
-                    for (int j4 = 0; j4 < NB / 4; ++j4) {
-                        const f32x4 bj = *reinterpret_cast<const f32x4 *>(L.state_b + 4 * j4);
-                        const f32x4 w0 = fw[j4], w1 = fw[NB / 4 + j4];
-                        s1 += w0.x * bj.x; s2 += w1.x * bj.x;
-                        s1 += w0.y * bj.y; s2 += w1.y * bj.y;
-                        s1 += w0.z * bj.z; s2 += w1.z * bj.z;
-                        s1 += w0.w * bj.w; s2 += w1.w * bj.w;
-                    }
-                    float t1, t2;
-                    dss_tanh_approx2(L.tansig, s1, s2, t1, t2);
-                    s1 = ff0 * t1;
-                    s2 = ff1 * t2;
-                    s1 += s2;
-                    const bool bit = thr_lv < s1;
-                    const unsigned long long mask = __ballot(bit);
-                    if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
-                }
-                __syncthreads();                                                        // barrier D
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[7] += t - ta; ta = t; }
-                cur ^= 1;
-            }
-        }
-        __syncthreads();                                                                // final barrier
-        if (STAMP && lane == 0 && b.trace_exc)
-            for (int k = 0; k < 8; ++k) b.trace_exc[((size_t)utt * 6 + wave) * 8 + k] = (float)sa[k];
-        b.gru_a_state[(size_t)slot * NA + unit] = st;
+    if (wave < 4) {
+        dss_role_a<TRACE, STAMP, (Z < 8 ? Z : 8), true>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane);
+    } else if (wave < 6) {
+        dss_role_a<TRACE, STAMP, Z, false>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane);
     } else if (wave == 6) {
         // =====================================================================================================
         // role B1: GRU B over inputs 0..207, lane = row (0..15 z, 16..31 r, 32..47 h)
