@@ -226,3 +226,26 @@ def test_ragged_argument_errors(model):
         gpu.synthesize_ragged([f], slots=[4])
     with pytest.raises(_lib.DssError, match="frames"):
         gpu.synthesize_ragged([synthetic_features(1, 6)])
+
+
+def test_long_utterance_and_extreme_features(oracle, model):
+    """A 3-second utterance (no drift over 48 000 samples) and features at the edges of what the frame network accepts:
+    pitch values that clamp to index 33 and 255, large cepstra (LPC recursion under stress, tanh/sigmoid tables at their
+    clamps) and an all-zero row -- all bit-exact against the oracle."""
+    from dss_amd.lpcnet import LPCNetBatch
+    F = 300
+    long_f = synthetic_features(4242, F)
+    edge = synthetic_features(4243, 40)
+    edge[5:10, 18] = -10.0                          # pitch index clamps to 33
+    edge[10:15, 18] = 10.0                          # ... and to 255
+    edge[15:20, :18] *= 6.0                         # hot cepstrum
+    edge[20:25, :] = 0.0
+    edge[25:30, 19] = 3.0
+    got_long = LPCNetBatch(1, F).synthesize(long_f[None])[0]
+    dec = oracle.decoder(model)
+    want_long = np.concatenate([dec.synthesize(long_f[t]) for t in range(F)])
+    assert np.array_equal(got_long, want_long)
+    got_edge = LPCNetBatch(1, 40).synthesize(edge[None])[0]
+    dec = oracle.decoder(model)
+    want_edge = np.concatenate([dec.synthesize(edge[t]) for t in range(40)])
+    assert np.array_equal(got_edge, want_edge)
