@@ -209,8 +209,9 @@ struct SampleLds {
             b.trace_exc[o] = (float)upd_exc;                                                     \
             b.trace_pcm[o] = pcm;                                                                \
         }                                                                                        \
-        _Pragma("unroll") for (int j = DSS_LPC_ORDER - 1; j > 0; --j) last_sig[j] = last_sig[j - 1]; \
-        last_sig[0] = pcm;                                                                       \
+        /* signal history: element j lives in lane j; shift by one lane (row_shr:1), lane 0 keeps the new sample */ \
+        ls_lane = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, pcm),   \
+                                     __builtin_bit_cast(int, ls_lane), 0x111, 0xf, 0xf, false));  \
         last_exc = upd_exc;                                                                      \
         pcm += 0.85f * deemph;                                                                   \
         deemph = pcm;                                                                            \
@@ -472,9 +473,9 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         const int row = lane < NB3 ? lane : 0;
         __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
         const float gbb1 = m.gru_b_bias[NB3 + row];
-        float last_sig[DSS_LPC_ORDER], lpc[DSS_LPC_ORDER];
-#pragma unroll
-        for (int j = 0; j < DSS_LPC_ORDER; ++j) { last_sig[j] = b.last_sig[(size_t)slot * DSS_LPC_ORDER + j]; lpc[j] = 0.f; }
+        // signal history and LPC of the current frame, element j in lane j (j < 16): one register each instead of 32,
+        // a one-instruction shift per sample, and lane j publishes element j for the speculation as it is
+        float ls_lane = b.last_sig[(size_t)slot * DSS_LPC_ORDER + (lane & (DSS_LPC_ORDER - 1))], lpc_lane = 0.f;
         float deemph = b.deemph[slot];
         int last_exc = b.last_exc[slot];
         DssKiss99 rng = {b.rng[slot * 4 + 0], b.rng[slot * 4 + 1], b.rng[slot * 4 + 2], b.rng[slot * 4 + 3]};
@@ -497,15 +498,16 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 continue;
             }
             const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;
-#pragma unroll
-            for (int j = 0; j < DSS_LPC_ORDER; ++j) lpc[j] = fo[3 * NA + NB3 + j];
+            lpc_lane = fo[3 * NA + NB3 + (lane & (DSS_LPC_ORDER - 1))];
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
                 if (STAMP) t_prev = __builtin_readcyclecounter();
                 if (!have_spec) {        // first sample of the call: prediction and indices computed directly
                     pred = 0;
 #pragma unroll
-                    for (int j = 0; j < DSS_LPC_ORDER; ++j) pred -= last_sig[j] * lpc[j];
-                    const int su = dss_lin2ulaw(last_sig[0]);
+                    for (int j = 0; j < DSS_LPC_ORDER; ++j)
+                        pred -= __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls_lane), j)) *
+                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lpc_lane), j));
+                    const int su = dss_lin2ulaw(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls_lane), 0)));
                     const int pu = dss_lin2ulaw(pred);
                     if (lane == 0) { L.idx[0] = su; L.idx[1] = pu; L.idx[2] = last_exc; }
                 }
@@ -525,12 +527,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 {   // inputs of the speculation the GRU A waves run between barriers B and C
                     const bool last_of_frame = (i == DSS_FRAME_SIZE - 1);
                     next_exists = !(last_of_frame && f == nf - 1);
-                    float lp = lpc[0];                       // lane j < 16 publishes element j
-#pragma unroll
-                    for (int j = 1; j < DSS_LPC_ORDER; ++j) lp = (lane == j) ? lpc[j] : lp;
-                    float ls = last_sig[0];
-#pragma unroll
-                    for (int j = 1; j < DSS_LPC_ORDER; ++j) ls = (lane == j) ? last_sig[j] : ls;
+                    float lp = lpc_lane;                     // lane j < 16 publishes element j
+                    const float ls = ls_lane;
                     if (last_of_frame && next_exists && lane < DSS_LPC_ORDER)
                         lp = b.frame_out[((size_t)utt * n_frames + f + 1) * DSS_COND_STRIDE + 3 * NA + NB3 + lane];
                     if (lane < DSS_LPC_ORDER) { L.spec_lpc[lane] = lp; L.spec_ls[lane] = ls; }
@@ -639,9 +637,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         if (STAMP && lane == 0 && b.trace_pcm)          // diagnostic build only
             for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)utt * 6 + k] = (float)stamp_acc[k];
         if (lane < NB) b.gru_b_state[(size_t)slot * NB + lane] = L.state_b[lane];
+        if (lane < DSS_LPC_ORDER) b.last_sig[(size_t)slot * DSS_LPC_ORDER + lane] = ls_lane;
         if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < DSS_LPC_ORDER; ++j) b.last_sig[(size_t)slot * DSS_LPC_ORDER + j] = last_sig[j];
             b.deemph[slot] = deemph;
             b.last_exc[slot] = last_exc;
             b.rng[slot * 4 + 0] = rng.z; b.rng[slot * 4 + 1] = rng.w; b.rng[slot * 4 + 2] = rng.jsr; b.rng[slot * 4 + 3] = rng.jcong;
