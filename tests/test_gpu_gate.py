@@ -1,6 +1,10 @@
 """GPU tests of the speech-segment gate: csrc/speech_gate.hip through the C ABI against the
-numpy ring-buffer classes of local/common.py (themselves pinned by hand-derived known answers in test_cpu_local.py),
-and the gated many-stream pipeline against the per-stream composition the reference's graph performs."""
+CPU restatement in oracle/speech_gate_oracle.py (pinned by hand-derived known answers in test_cpu_local.py), and the
+gated many-stream pipeline against the per-stream composition the reference's graph performs."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import asyncio
 
 import numpy as np
@@ -13,9 +17,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _host_gate(C, N, ctx, sm_ctx):
-    from local.common import SpeechSegmentHistory, VoiceActivityDetectionSmoothing
-    return (VoiceActivityDetectionSmoothing(nb_features=C, context_frames=sm_ctx),
-            SpeechSegmentHistory(nb_features=C, buffer_size=N, context=ctx))
+    from speech_gate_oracle import SpeechGateOracle
+    return SpeechGateOracle(C, N, ctx, sm_ctx)
 
 
 @pytest.mark.parametrize("C,N,ctx,sm_ctx", [(64, 2000, 50, 5), (5, 37, 3, 2), (70, 16, 0, 0), (3, 23, 4, 1)])
@@ -39,11 +42,9 @@ def test_gate_matches_numpy_rings_bit_exact(C, N, ctx, sm_ctx):
             labels[:, i] = state
         got, n_speech = gate.push(frames, labels)
         for s in range(S):
-            sm, hist = host[s]
-            data, lab = sm.insert(data=frames[s], speech_labels=labels[s])
-            want = hist.insert(data=data, speech_labels=lab)
+            want, want_speech = host[s].push(frames[s], labels[s])
             assert len(got[s]) == len(want), (tick, s)
-            assert n_speech[s] == np.count_nonzero(lab)
+            assert n_speech[s] == want_speech
             for a, b in zip(got[s], want):
                 assert a.dtype == np.float32 and a.shape == b.shape and np.array_equal(a, b), (tick, s)
             n_seg += len(want)
@@ -122,14 +123,14 @@ def test_gated_streaming_pipeline_against_per_stream_composition(oracle):
         counter += W
         want = []
         for s in range(S):
-            data, lab = host[s][0].insert(data=z[s], speech_labels=labels[s])
-            for seg in host[s][1].insert(data=data, speech_labels=lab):
+            segs, n_sp = host[s].push(z[s], labels[s])
+            for seg in segs:
                 with torch.no_grad():
                     y, _ = pipe.decoder(torch.from_numpy(seg)[None].cuda(),
                                         pipe.decoder.create_new_initial_state(batch_size=1, device="cuda"))
                 feats = y[0].cpu().numpy()
                 pcm = np.concatenate([vocoders[s].synthesize(feats[t]) for t in range(len(feats))])
-                want.append((s, counter - len(seg) - (W - np.count_nonzero(lab)), pcm))
+                want.append((s, counter - len(seg) - (W - n_sp), pcm))
         assert [(s, p) for s, p, _ in got] == [(s, p) for s, p, _ in want], k
         for (_, _, a), (_, _, b) in zip(got, want):
             assert a.dtype == np.int16 and np.array_equal(a, b), k
