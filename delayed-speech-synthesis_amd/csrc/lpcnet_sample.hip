@@ -200,6 +200,35 @@ struct SampleLds {
         acc += p1.y;                                                                             \
     }
 
+// Tree walk over the 256 decision bits the dual-FC waves left in L.bits: every operand is wave-uniform, so this is scalar
+// bit arithmetic.  8 levels, 3 scalar instructions each: test the node's bit (s_bitcmp1_b64 -> SCC), val = 2*val + SCC
+// (s_addc_u32), next node index.  Nodes 1..63 live in m0, 64..127 in m1, 128..191 in m2, 192..255 in m3.
+#define DSS_TREE_WALK(VAL)                                                                       \
+    {                                                                                            \
+        const uint4 b0 = *reinterpret_cast<const uint4 *>(&L.bits[0]);                           \
+        const uint4 b1 = *reinterpret_cast<const uint4 *>(&L.bits[4]);                           \
+        const unsigned long long m0 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.x); \
+        const unsigned long long m1 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.z); \
+        const unsigned long long m2 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.x); \
+        const unsigned long long m3 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.z); \
+        int tnode_;                                                                              \
+        unsigned long long mm_;                                                                  \
+        asm volatile(                                                                            \
+            "s_mov_b32 %0, 0\n\t"                                                                \
+            "s_bitcmp1_b64 %3, 1\n\t"          "s_addc_u32 %0, %0, %0\n\t"                       \
+            "s_or_b32 %1, %0, 2\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_or_b32 %1, %0, 4\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_or_b32 %1, %0, 8\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_or_b32 %1, %0, 16\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_or_b32 %1, %0, 32\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_bitcmp1_b64 %4, %0\n\t"         "s_addc_u32 %0, %0, %0\n\t"                       \
+            "s_cmp_lt_u32 %0, 64\n\t"          "s_cselect_b64 %2, %5, %6\n\t"                    \
+            "s_bitcmp1_b64 %2, %0\n\t"         "s_addc_u32 %0, %0, %0"                            \
+            : "=&s"(VAL), "=&s"(tnode_), "=&s"(mm_)                                              \
+            : "s"(m0), "s"(m1), "s"(m2), "s"(m3)                                                 \
+            : "scc");                                                                            \
+    }
+
 // wave 7: fold the sampled excitation into the signal history and emit the PCM sample (lpcnet_synthesize_tail_impl)
 #define DSS_S_UPDATE()                                                                           \
     {                                                                                            \
@@ -270,6 +299,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
     float st = L.state_a[0][unit];
     unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
     f32x4 PR[2 * ZRC];                                           // z/r block products of the coming sample
+    bool first_sample = true;
     DSS_H_CHAIN(L.state_a[0])                                    // first sample of this call
     DSS_ZR_PRODUCTS(L.state_a[0])
     __syncthreads();                                             // L.ah of every unit visible to its z/r lane
@@ -288,10 +318,23 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             float az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
             float ar = rbr + dgr * st;
             const float ahv = L.ah[unit];                        // this unit's h-gate pre-activation (its h lane, B..C)
-            __syncthreads();                                                        // barrier A
+            // The three embedding indices.  First sample of a call: wave 7 computes them and hands them over through
+            // L.idx and barrier A.  Every later sample: this wave walks the sampling tree itself (the same scalar
+            // code wave 7 runs for its bookkeeping) and looks the speculated indices up, so neither a barrier nor
+            // wave 7 stands between the dual-FC and the embedding loads.
+            int si, pi, ei;
+            if (first_sample) {
+                __syncthreads();                                                    // barrier A (first sample only)
+                si = L.idx[0]; pi = L.idx[1]; ei = L.idx[2];
+                first_sample = false;
+            } else {
+                int exc_;
+                DSS_TREE_WALK(exc_)
+                const unsigned sidx = __builtin_amdgcn_readfirstlane((unsigned)L.spec_tab_idx[exc_]);
+                si = (int)(sidx & 0xFF); pi = (int)(sidx >> 8); ei = exc_;
+            }
             if (STAMP) ta = __builtin_readcyclecounter();
             {
-                const int si = L.idx[0], pi = L.idx[1], ei = L.idx[2];
                 // 32-bit element offsets from the (scalar) table bases: no 64-bit per-lane pointers to keep alive
                 const unsigned so = (unsigned)si * (3 * NA) + (unsigned)unit;
                 const unsigned po = (unsigned)pi * (3 * NA) + (unsigned)unit;
@@ -448,7 +491,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
                 float acc = gbb0 + gbc;                                                 // compute_gruB
                 ++seq;
-                __syncthreads();                                                        // barrier A
+                if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
                 __syncthreads();                                                        // barrier B
                 const float *an = L.state_a[cur ^ 1];
                 DSS_GB_CHAIN(an, GBH6)
@@ -513,7 +556,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 }
                 ++seq;
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[0] += t - t_prev; t_prev = t; }
-                __syncthreads();                                                        // barrier A
+                if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[1] += t - t_prev; t_prev = t; }
                 if (upd_pending) { DSS_S_UPDATE() }                                     // previous sample's bookkeeping
                 {   // off the critical path: this sample's 8 thresholds and GRU B's recurrent half
@@ -590,37 +633,12 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 __syncthreads();                                                        // barrier D
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[4] += t - t_prev; t_prev = t; }
                 cur ^= 1;
-                // walk the tree: every operand is wave-uniform, so this is scalar bit arithmetic
-                const uint4 b0 = *reinterpret_cast<const uint4 *>(&L.bits[0]);
-                const uint4 b1 = *reinterpret_cast<const uint4 *>(&L.bits[4]);
-                const unsigned long long m0 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.x);
-                const unsigned long long m1 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.z);
-                const unsigned long long m2 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.x);
-                const unsigned long long m3 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.z);
-                // 8 levels, 3 scalar instructions each: test the node's bit (s_bitcmp1_b64 -> SCC), val = 2*val + SCC
-                // (s_addc_u32), next node index.  Nodes 1..63 live in m0, 64..127 in m1, 128..191 in m2, 192..255 in m3.
-                int val, tnode;
-                unsigned long long mm;
-                asm volatile(
-                    "s_mov_b32 %0, 0\n\t"
-                    "s_bitcmp1_b64 %3, 1\n\t"          "s_addc_u32 %0, %0, %0\n\t"
-                    "s_or_b32 %1, %0, 2\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
-                    "s_or_b32 %1, %0, 4\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
-                    "s_or_b32 %1, %0, 8\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
-                    "s_or_b32 %1, %0, 16\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
-                    "s_or_b32 %1, %0, 32\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t"
-                    "s_bitcmp1_b64 %4, %0\n\t"         "s_addc_u32 %0, %0, %0\n\t"
-                    "s_cmp_lt_u32 %0, 64\n\t"          "s_cselect_b64 %2, %5, %6\n\t"
-                    "s_bitcmp1_b64 %2, %0\n\t"         "s_addc_u32 %0, %0, %0"
-                    : "=&s"(val), "=&s"(tnode), "=&s"(mm)
-                    : "s"(m0), "s"(m1), "s"(m2), "s"(m3)
-                    : "scc");
+                int val;
+                DSS_TREE_WALK(val)
                 const int exc = val;
                 // the next sample's prediction and mu-law indices were precomputed for every possible exc
-                const unsigned sidx = L.spec_tab_idx[exc];
-                const float pred_next = L.spec_tab_pred[exc];
+                const float pred_next = L.spec_tab_pred[exc];     // (the GRU A waves look the mu-law indices up themselves)
                 have_spec = next_exists;
-                if (have_spec && lane == 0) { L.idx[0] = (int)(sidx & 0xFF); L.idx[1] = (int)(sidx >> 8); L.idx[2] = exc; }
                 // Everything below only updates this wave's own state; except at the end of a frame (whose PCM is
                 // copied out right after the loop) it is deferred until after the next barrier A, off the path
                 // that the GRU A waves are waiting on.
