@@ -35,6 +35,9 @@
 #define GBH7 112                          // ... in wave 7's VGPRs (208..319); wave 7 also carries the scalar state
 #define GBHL (NA - GBH6 - GBH7)           // ... and the last 64 inputs' weights in LDS, [row][GBL_STRIDE]
 #define GBL_STRIDE 68
+#ifndef GBP
+#define GBP 48                            // ... of wave 7's inputs, the first GBP are multiplied while it waits for wave 6
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -149,6 +152,15 @@ struct SampleLds {
         acc += p1.x;                                                                             \
         acc += p1.y;                                                                             \
     }
+#define DSS_GB_GROUP_OFF(AV, G, WOFF)                                                            \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+        const f32x2 p0 = WB[(WOFF) + 2 * (4 * (G) + u)] * (AV)[u].lo;                            \
+        const f32x2 p1 = WB[(WOFF) + 2 * (4 * (G) + u) + 1] * (AV)[u].hi;                        \
+        acc += p0.x;                                                                             \
+        acc += p0.y;                                                                             \
+        acc += p1.x;                                                                             \
+        acc += p1.y;                                                                             \
+    }
 #define DSS_GB_LOAD(AV, AN, G)                                                                   \
     _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
         (AV)[u] = *reinterpret_cast<const f32x4 *>((AN) + 16 * (G) + 4 * u);
@@ -177,6 +189,27 @@ struct SampleLds {
                 if (g + 2 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                   \
                 __builtin_amdgcn_sched_barrier(0);                                               \
                 DSS_GB_GROUP(avB, g + 1)                                                         \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+
+// ... and with the weights taken from WB[WOFF + ...] (a chain that starts in the middle of the lane's weights)
+#define DSS_GB_CHAIN_RUN_OFF(AN, N, WOFF)                                                                  \
+    {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < (N) / 16; g += 2) {                                \
+            if (g + 1 < (N) / 16) DSS_GB_LOAD(avB, AN, g + 1)                                    \
+            __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch ahead of the arithmetic */ \
+            if (g + 1 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                       \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_GB_GROUP_OFF(avA, g, WOFF)                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 2 < (N) / 16) DSS_GB_LOAD(avA, AN, g + 2)                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 1 < (N) / 16) {                                                              \
+                if (g + 2 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                   \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                DSS_GB_GROUP_OFF(avB, g + 1, WOFF)                                                         \
             }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
@@ -582,15 +615,41 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 for (int j = 0; j < NB; ++j) rec += L.gb_wrec[j * NB3 + row] * L.state_b[j];
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[2] += t - t_prev; t_prev = t; }
+                // While wave 6 runs the first half of the chain, this wave forms the products of its first GBP inputs (it
+                // has about 1900 idle cycles and, until its own part of the chain starts, the registers of the prefetch
+                // buffers): when wave 6 hands over, those inputs cost one sum each instead of 1.8 instructions.
                 const float *an = L.state_a[cur ^ 1] + GBH6;
+                f32x4 PQ[GBP / 4];
+#pragma unroll
+                for (int g = 0; g < GBP / 16; ++g) {
+                    f32x4 xq[4];
+                    DSS_GB_LOAD(xq, an, g)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        PQ[4 * g + u].lo = WB[2 * (4 * g + u)] * xq[u].lo;
+                        PQ[4 * g + u].hi = WB[2 * (4 * g + u) + 1] * xq[u].hi;
+                    }
+                    // pinned: left alone, the compiler sinks the multiplications below the hand-off wait
+                    asm volatile("" : "+v"(PQ[4 * g].x), "+v"(PQ[4 * g].y), "+v"(PQ[4 * g].z), "+v"(PQ[4 * g].w),
+                                      "+v"(PQ[4 * g + 1].x), "+v"(PQ[4 * g + 1].y), "+v"(PQ[4 * g + 1].z), "+v"(PQ[4 * g + 1].w),
+                                      "+v"(PQ[4 * g + 2].x), "+v"(PQ[4 * g + 2].y), "+v"(PQ[4 * g + 2].z), "+v"(PQ[4 * g + 2].w),
+                                      "+v"(PQ[4 * g + 3].x), "+v"(PQ[4 * g + 3].y), "+v"(PQ[4 * g + 3].z), "+v"(PQ[4 * g + 3].w));
+                }
                 f32x4 avA[4], avB[4];
-                DSS_GB_LOAD(avA, an, 0)                      // the new GRU A state is there since barrier B
+                DSS_GB_LOAD(avA, an + GBP, 0)                // first state group of the part it multiplies on the fly
                 __builtin_amdgcn_sched_barrier(0);
                 while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
-                    __builtin_amdgcn_s_sleep(1);
+                    ;                                    // tight poll: one LDS round trip per iteration is pause enough
                 float acc = L.gb_acc[lane];
+#pragma unroll
+                for (int q = 0; q < GBP / 4; ++q) {
+                    acc += PQ[q].x;
+                    acc += PQ[q].y;
+                    acc += PQ[q].z;
+                    acc += PQ[q].w;
+                }
                 {
-                    DSS_GB_CHAIN_RUN(an, GBH7)
+                    DSS_GB_CHAIN_RUN_OFF(an + GBP, GBH7 - GBP, GBP / 2)
                     const float *al = an + GBH7, *wl = L.gb_wl + row * GBL_STRIDE;
                     f32x4 tA[4], tB[4];                   // [0..1] state, [2..3] weights of two groups of 4 inputs
                     DSS_GBL_LOAD(tA, 0)
