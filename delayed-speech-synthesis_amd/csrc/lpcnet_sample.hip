@@ -325,8 +325,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
         fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
         ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
     }
-    const int cand = tid & 127;                                  // waves 4, 5: excitation candidates cand, cand+128
-    const float u2l_a = L.ulaw2lin[cand], u2l_b = L.ulaw2lin[cand + 128];
+    const float u2l_c = L.ulaw2lin[(HAS_FC ? 128 + tid : tid - 256) & 255];   // this lane's excitation candidate (waves 0, 1, 4, 5)
     const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
     int cur = 0;
     float st = L.state_a[0][unit];
@@ -409,26 +408,21 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
             DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
             DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
-            if constexpr (!HAS_FC) {
-                // Speculation over all 256 possible excitation values of THIS sample (waves 4 and 5, two
-                // candidates per lane): the next sample's LPC prediction and mu-law indices, so that once the
-                // tree walk has picked the value, wave 7 only looks the result up instead of running two
-                // ~40-step dependent chains.  Same expressions, same order as lpcnet_synthesize_tail_impl().
-                const float sp = L.spec_pred;
-                const float pcm_a = sp + u2l_a, pcm_b = sp + u2l_b;
-                const float l0 = L.spec_lpc[0];
-                float pa = 0, pb = 0;
-                pa -= pcm_a * l0; pb -= pcm_b * l0;
+            if (wave >= 4 || wave < 2) {
+                // Speculation over all 256 possible excitation values of THIS sample, one candidate per lane of waves 4, 5
+                // (candidates 0..127) and of waves 0, 1, which have the lightest B..C load of the dual-FC waves
+                // (128..255): the next sample's LPC prediction and mu-law indices, so that once the tree walk has
+                // picked the value nobody has to run the two ~40-step dependent chains.  Same expressions, same order
+                // as lpcnet_synthesize_tail_impl().
+                const int cand = HAS_FC ? 128 + tid : tid - 256;
+                const float pcm_c = L.spec_pred + u2l_c;
+                float pc = 0;
+                pc -= pcm_c * L.spec_lpc[0];
 #pragma unroll
-                for (int j = 1; j < DSS_LPC_ORDER; ++j) {
-                    const float t2 = L.spec_ls[j - 1] * L.spec_lpc[j];          // same product for every candidate
-                    pa -= t2; pb -= t2;
-                }
-                const int su_a = dss_lin2ulaw(pcm_a), su_b = dss_lin2ulaw(pcm_b);
-                const int pu_a = dss_lin2ulaw(pa), pu_b = dss_lin2ulaw(pb);
-                L.spec_tab_pred[cand] = pa; L.spec_tab_pred[cand + 128] = pb;
-                L.spec_tab_idx[cand] = (unsigned short)(su_a | (pu_a << 8));
-                L.spec_tab_idx[cand + 128] = (unsigned short)(su_b | (pu_b << 8));
+                for (int j = 1; j < DSS_LPC_ORDER; ++j) pc -= L.spec_ls[j - 1] * L.spec_lpc[j];
+                const int su_c = dss_lin2ulaw(pcm_c), pu_c = dss_lin2ulaw(pc);
+                L.spec_tab_pred[cand] = pc;
+                L.spec_tab_idx[cand] = (unsigned short)(su_c | (pu_c << 8));
             }
             if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
             __syncthreads();                                                        // barrier C
