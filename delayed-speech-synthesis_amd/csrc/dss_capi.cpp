@@ -376,6 +376,17 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         m.hblk_floats = hfloats;
         int *di; float *df; unsigned *du;
         rc = dev_upload<int>(unit_of.data(), unit_of.size(), &di); if (rc) return rc; m.unit_of = di;
+        {   // embedding rows permuted into lane order, the three gates of a lane's unit side by side
+            const float *tabs[3] = {v.embed_sig, v.embed_pred, v.embed_exc};
+            std::vector<float> perm((size_t)256 * NA * 3);
+            for (int t = 0; t < 3; ++t) {
+                for (int idx = 0; idx < 256; ++idx)
+                    for (int tid = 0; tid < NA; ++tid)
+                        for (int g = 0; g < 3; ++g)
+                            perm[((size_t)idx * NA + tid) * 3 + g] = tabs[t][(size_t)idx * 3 * NA + (size_t)g * NA + unit_of[tid]];
+                rc = dev_upload<float>(perm.data(), perm.size(), &df); if (rc) return rc; m.embed_lane[t] = df;
+            }
+        }
         rc = dev_upload<int>(unit_h.data(), unit_h.size(), &di); if (rc) return rc; m.unit_h = di;
         rc = dev_upload<int>(wave_nh.data(), wave_nh.size(), &di); if (rc) return rc; m.wave_nh = di;
         rc = dev_upload<int>(wave_hoff.data(), wave_hoff.size(), &di); if (rc) return rc; m.wave_hoff = di;

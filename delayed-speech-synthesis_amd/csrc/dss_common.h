@@ -51,6 +51,8 @@ struct DssModelDev {
     const float *gru_a_dense_w, *gru_a_dense_b, *gru_b_dense_w, *gru_b_dense_b;
     // sample-rate network
     const float *embed_sig, *embed_pred, *embed_exc;        // [256][1152]
+    const float *embed_lane[3];   // the same three tables as [256][384 lanes][3 gates] in the fast kernel's lane order: one
+                                  // 12-byte load per lane and table, 768 contiguous bytes per wave
     const float *gru_a_rbias, *gru_a_diag;                  // [1152]
     DssSparseGate gate[3];
     const float *gru_b_bias;                                // [2][48]

@@ -367,14 +367,13 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             }
             if (STAMP) ta = __builtin_readcyclecounter();
             {
-                // 32-bit element offsets from the (scalar) table bases: no 64-bit per-lane pointers to keep alive
-                const unsigned so = (unsigned)si * (3 * NA) + (unsigned)unit;
-                const unsigned po = (unsigned)pi * (3 * NA) + (unsigned)unit;
-                const unsigned eo = (unsigned)ei * (3 * NA) + (unsigned)unit;
-                // the nine embedding values of this lane
-                const float es0 = m.embed_sig[so], es1 = m.embed_sig[so + NA], es2 = m.embed_sig[so + 2 * NA];
-                const float ep0 = m.embed_pred[po], ep1 = m.embed_pred[po + NA], ep2 = m.embed_pred[po + 2 * NA];
-                const float ee0 = m.embed_exc[eo], ee1 = m.embed_exc[eo + NA], ee2 = m.embed_exc[eo + 2 * NA];
+                // the nine embedding values of this lane: three 12-byte loads from the lane-ordered copies of the tables
+                // (m.embed_lane: [index][lane][gate]), 768 contiguous bytes per wave and table
+                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                const f32x3 es = *reinterpret_cast<const f32x3 *>(m.embed_lane[0] + ((unsigned)si * NA + (unsigned)tid) * 3);
+                const f32x3 ep = *reinterpret_cast<const f32x3 *>(m.embed_lane[1] + ((unsigned)pi * NA + (unsigned)tid) * 3);
+                const f32x3 ee = *reinterpret_cast<const f32x3 *>(m.embed_lane[2] + ((unsigned)ei * NA + (unsigned)tid) * 3);
+                const float es0 = es.x, es1 = es.y, es2 = es.z, ep0 = ep.x, ep1 = ep.y, ep2 = ep.z, ee0 = ee.x, ee1 = ee.y, ee2 = ee.z;
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[0] += t - ta; ta = t; }
                 const float gz = ((cz + es0) + ep0) + ee0;                          // compute_gru_a_input
                 const float gr = ((cr + es1) + ep1) + ee1;
