@@ -365,6 +365,9 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 const unsigned sidx = __builtin_amdgcn_readfirstlane((unsigned)L.spec_tab_idx[exc_]);
                 si = (int)(sidx & 0xFF); pi = (int)(sidx >> 8); ei = exc_;
             }
+            // wave-uniform by construction: keep them scalar, so that the row offsets are SALU work and the loads take an
+            // SGPR base (the first-sample path would otherwise drag them into VGPRs)
+            si = __builtin_amdgcn_readfirstlane(si); pi = __builtin_amdgcn_readfirstlane(pi); ei = __builtin_amdgcn_readfirstlane(ei);
             if (STAMP) ta = __builtin_readcyclecounter();
             {
                 // the nine embedding values of this lane: three 12-byte loads from the lane-ordered copies of the tables
