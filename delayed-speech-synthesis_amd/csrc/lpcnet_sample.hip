@@ -5,21 +5,24 @@
 // src/nnet.c compute_gru_a_input / compute_sparse_gru / compute_gruB / sample_mdense (generic float path
 // of src/vec.h), as reached through the reference's binding extensions/lpcnet/cLPCNet.pxd:13.
 //
-// Where the ~300 KB of weights live for the whole launch (per sample only the three 1152-float embedding
-// rows come from L2):
-//   GRU A z- and r-gate 8x4 blocks (15k floats)  VGPRs of waves 0..5 (lane = unit, 2 x DSS_ZRC slots)
+// Where the ~300 KB of weights live for the whole launch (per sample only three embedding rows come from L2,
+// as one 12-byte load per lane and table from lane-ordered copies of the tables):
+//   GRU A z- and r-gate 8x4 blocks (15k floats)  VGPRs of waves 0..5 (lane = unit; 8 slots per gate on waves 0..3,
+//                                                 all DSS_ZRC on waves 4..5, which get the heaviest row groups)
 //   GRU A h-gate 8x4 blocks (30k floats)          LDS, one 128-byte record per block, grouped per wave
-//   GRU B input weights (18k floats)              VGPRs of waves 6 and 7 (lane = row; 208 + 128 inputs), last 64 in LDS
+//   GRU B input weights (18k floats)              VGPRs of waves 6 and 7 (lane = row; 208 + 112 inputs), last 64 in LDS
 //   dual-FC (8k floats)                           VGPRs of waves 0..3 (lane = tree node)
-// Roles inside the 512-thread workgroup (8 waves, 2 per SIMD); every wave runs the same barrier sequence
-// A B C D per sample:
-//   waves 0..5  GRU A.  A..B: embedding rows, z and r chains, activations, new state.  B..C: the h-gate
-//               recurrent chain of the NEXT sample (needs only the new state) -- hidden under GRU B.
+// Roles inside the 512-thread workgroup (8 waves, 2 per SIMD); three workgroup barriers B C D per sample (a fourth,
+// A, only on the first sample of a call):
+//   waves 0..5  GRU A (dss_role_a, compiled once with and once without the dual-FC).  D..B: tree walk over the
+//               decision bits, speculated embedding indices, embedding rows, z and r chains, activations, new state.
+//               B..C: the h-gate recurrent chain and the z/r block products of the NEXT sample (they need only the
+//               new state) and the speculation over the 256 possible excitations -- hidden under GRU B.
 //               C..D (waves 0..3): dual-FC logits of all 255 tree nodes -> decision bits.
 //   wave 6      GRU B, inputs 0..207: lane = output row, one sequential chain per row, then hands the partial
 //               sums to wave 7 through LDS (flag, no barrier).
-//   wave 7      GRU B inputs 208..383 + gates, and the scalar recurrences: order-16 LPC prediction, mu-law,
-//               de-emphasis, kiss99 thresholds, tree walk, PCM output.
+//   wave 7      GRU B inputs 208..383 (the products of the first 48 formed while it waits for wave 6) + gates, and
+//               the scalar recurrences: mu-law / de-emphasis / PCM bookkeeping, kiss99 thresholds, its own tree walk.
 // Summation order inside every row is exactly the C source's (one product at a time, ascending input),
 // and the library is built with -ffp-contract=off, so results are bit-identical to the scalar C path.
 #include "dss_common.h"
