@@ -319,12 +319,17 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
     const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + uh];
     const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + uh];
     // dual-FC constants of tree node `tid` (waves 0..3)
-    f32x4 fw[HAS_FC ? 2 * NB / 4 : 1];
+    // the two dense layers of the node run as the two halves of packed fp32 instructions: weights as pairs
+    // (layer 0 input j, layer 1 input j), the two running sums as one register pair
+    f32x2 fw[HAS_FC ? NB : 1];
     float fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
     if constexpr (HAS_FC) {
         const int node = tid;
 #pragma unroll
-        for (int k = 0; k < 2 * NB / 4; ++k) fw[k] = *reinterpret_cast<const f32x4 *>(m.fc_w + (size_t)node * 2 * NB + 4 * k);
+        for (int j = 0; j < NB; ++j) {
+            fw[j].x = m.fc_w[(size_t)node * 2 * NB + j];
+            fw[j].y = m.fc_w[(size_t)node * 2 * NB + NB + j];
+        }
         fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
         ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
     }
@@ -434,16 +439,23 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
             if constexpr (HAS_FC) {                                                 // sample_mdense, all nodes
                 const float thr_lv = L.thr[level];                                  // issued first, used last
-                float s1 = fb0, s2 = fb1;
+                f32x2 s12 = {fb0, fb1};
 #pragma unroll
                 for (int j4 = 0; j4 < NB / 4; ++j4) {
                     const f32x4 bj = *reinterpret_cast<const f32x4 *>(L.state_b + 4 * j4);
-                    const f32x4 w0 = fw[j4], w1 = fw[NB / 4 + j4];
-                    s1 += w0.x * bj.x; s2 += w1.x * bj.x;
-                    s1 += w0.y * bj.y; s2 += w1.y * bj.y;
-                    s1 += w0.z * bj.z; s2 += w1.z * bj.z;
-                    s1 += w0.w * bj.w; s2 += w1.w * bj.w;
+                    // per input: one packed product for both layers, one packed sum (each half rounds on its own,
+                    // exactly as the two scalar chains did)
+                    // (the four products first: a packed result needs a wait state before it can be read)
+                    const f32x2 q0 = fw[4 * j4 + 0] * (f32x2){bj.x, bj.x};
+                    const f32x2 q1 = fw[4 * j4 + 1] * (f32x2){bj.y, bj.y};
+                    const f32x2 q2 = fw[4 * j4 + 2] * (f32x2){bj.z, bj.z};
+                    const f32x2 q3 = fw[4 * j4 + 3] * (f32x2){bj.w, bj.w};
+                    s12 += q0;
+                    s12 += q1;
+                    s12 += q2;
+                    s12 += q3;
                 }
+                float s1 = s12.x, s2 = s12.y;
                 float t1, t2;
                 dss_tanh_approx2(L.tansig, s1, s2, t1, t2);
                 s1 = ff0 * t1;
