@@ -1,0 +1,172 @@
+"""Converter from xiph/LPCNet's generated ``src/nnet_data.c`` to the weight blob of include/dss_lpcnet_blob.h.
+
+The reference compiles that file into its extension (extensions/lpcnet/setup.py:34-36); xiph's ``autogen.sh`` downloads
+it, so it exists neither in the reference tree nor in this image.  This module is what a maintainer who has the file
+runs once::
+
+    python -m dss_amd.nnet_data path/to/LPCNet/src/nnet_data.c lpcnet.blob
+    DSS_LPCNET_WEIGHTS=lpcnet.blob python decode_online.py ...
+
+**Status: [UNVERIFIED] against a real nnet_data.c.**  The array names and layouts below are those of xiph's
+``dump_lpcnet.py`` output as of late 2021 (the era of the reference's translation-unit list), written down from the
+published sources; every array is checked for its exact size against the architecture constants, so a different
+revision fails loudly instead of producing a wrong model.  A name that differs can be remapped with ``names={...}``.
+What is tested here (tests/test_cpu_nnet_data.py) is the parser and the mapping on a synthetic file written in the same
+C syntax, including the ``#ifdef DOT_PROD`` / ``#else`` pairs xiph emits for quantisable layers (the ``#else`` branch,
+i.e. the float weights of the generic build, is the one taken -- the build the reference effectively uses).
+
+Layout facts relied on (xiph src/nnet.c, generic path):
+  * DenseLayer / conv1d ``input_weights``: input-major, ``w[i * nb_neurons + j]`` (sgemv_accum with stride = outputs);
+    conv1d inputs are [oldest frame | ... | newest frame].
+  * EmbeddingLayer: one row of ``dim`` floats per index.
+  * gru_a (sparse): ``recurrent_weights`` as 8x4 blocks ``[4 inputs][8 rows]`` in ``idx`` order, ``idx`` = per group of
+    8 rows a count followed by the first input column of each block; ``diag_weights[3N]``; ``bias[2 * 3N]`` of which
+    the second half (recurrent bias) is what compute_sparse_gru reads.
+  * gru_b: ``bias[2 * 3N]`` (input, recurrent), ``input_weights[384][48]``, ``recurrent_weights[16][48]``, both
+    input-major.
+  * dual_fc (MDenseLayer as sampled by sample_mdense): ``bias[2 * 256]``, ``factor[2 * 256]`` and
+    ``input_weights[256][2][16]`` (node, channel, input).
+"""
+from __future__ import annotations
+
+import re
+import sys
+from typing import Dict, Optional
+
+import numpy as np
+
+from .lpcnet_weights import LPCNetDims, pack_blob
+
+# blob key -> (C array name, dtype)
+DEFAULT_NAMES = {
+    "embed_pitch": "embed_pitch_weights",
+    "conv1_w": "feature_conv1_weights", "conv1_b": "feature_conv1_bias",
+    "conv2_w": "feature_conv2_weights", "conv2_b": "feature_conv2_bias",
+    "dense1_w": "feature_dense1_weights", "dense1_b": "feature_dense1_bias",
+    "dense2_w": "feature_dense2_weights", "dense2_b": "feature_dense2_bias",
+    "gru_a_dense_w": "gru_a_dense_feature_weights", "gru_a_dense_b": "gru_a_dense_feature_bias",
+    "gru_b_dense_w": "gru_b_dense_feature_weights", "gru_b_dense_b": "gru_b_dense_feature_bias",
+    "embed_sig": "gru_a_embed_sig_weights", "embed_pred": "gru_a_embed_pred_weights",
+    "embed_exc": "gru_a_embed_exc_weights",
+    "gru_a_bias": "gru_a_bias", "gru_a_diag": "gru_a_recurrent_weights_diag",
+    "gru_a_idx": "gru_a_recurrent_weights_idx", "gru_a_w": "gru_a_recurrent_weights",
+    "gru_b_bias": "gru_b_bias", "gru_b_w_in": "gru_b_weights", "gru_b_w_rec": "gru_b_recurrent_weights",
+    "dual_fc_bias": "dual_fc_bias", "dual_fc_w": "dual_fc_weights", "dual_fc_factor": "dual_fc_factor",
+}
+
+_ARRAY = re.compile(r"(?:static\s+)?const\s+(float|int|qweight|opus_int8|signed\s+char)\s+(\w+)\s*\[[^\]]*\]\s*=\s*\{(.*?)\}\s*;",
+                    re.S)
+
+
+def _strip_dot_prod(text: str) -> str:
+    """Keep the ``#else`` (float) branch of every ``#ifdef DOT_PROD`` block and drop other preprocessor lines."""
+    out, stack = [], []            # stack of [is_dot_prod_block, currently_in_else]
+    for line in text.splitlines():
+        t = line.strip()
+        if t.startswith("#if"):
+            stack.append([bool(re.match(r"#\s*ifdef\s+DOT_PROD\b", t)), False])
+            continue
+        if t.startswith("#else"):
+            if stack:
+                stack[-1][1] = True
+            continue
+        if t.startswith("#endif"):
+            if stack:
+                stack.pop()
+            continue
+        if t.startswith("#"):
+            continue
+        if any(is_dp and not in_else for is_dp, in_else in stack):
+            continue                # quantised (int8) variant: not the generic build
+        out.append(line)
+    return "\n".join(out)
+
+
+def parse_c_arrays(text: str) -> Dict[str, np.ndarray]:
+    """All ``const float/int NAME[...] = {...};`` initialisers of a C file -> {name: 1-D array}."""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    text = _strip_dot_prod(text)
+    arrays: Dict[str, np.ndarray] = {}
+    for ctype, name, body in _ARRAY.findall(text):
+        toks = [t for t in re.split(r"[\s,]+", body.strip()) if t]
+        if ctype == "int":
+            arrays[name] = np.array([int(t, 0) for t in toks], dtype=np.int32)
+        else:
+            arrays[name] = np.array([float(t.rstrip("fF")) for t in toks], dtype=np.float32)
+    return arrays
+
+
+def weights_from_nnet_data(text: str, dims: LPCNetDims = LPCNetDims(), names: Optional[Dict[str, str]] = None):
+    """C source text of nnet_data.c -> the dict ``pack_blob`` takes.  Raises ValueError naming the array on any size
+    mismatch."""
+    nm = dict(DEFAULT_NAMES)
+    nm.update(names or {})
+    arrays = parse_c_arrays(text)
+    d = dims
+    fin = d.nb_features + d.embed_pitch_dim
+    na, nb = d.gru_a, d.gru_b
+
+    def take(key, shape, dtype=np.float32):
+        cname = nm[key]
+        if cname not in arrays:
+            raise ValueError(f"array '{cname}' (for {key}) not found; arrays present: {sorted(arrays)[:8]} ...")
+        a = arrays[cname]
+        n = int(np.prod(shape))
+        if a.size != n:
+            raise ValueError(f"array '{cname}' has {a.size} elements, the architecture needs {n} {shape}")
+        return np.ascontiguousarray(a.astype(dtype).reshape(shape))
+
+    w: Dict[str, np.ndarray] = {}
+    w["embed_pitch"] = take("embed_pitch", (d.pitch_max, d.embed_pitch_dim))
+    w["conv1_w"] = take("conv1_w", (3 * fin, d.conv1_out)); w["conv1_b"] = take("conv1_b", (d.conv1_out,))
+    w["conv2_w"] = take("conv2_w", (3 * d.conv1_out, d.conv2_out)); w["conv2_b"] = take("conv2_b", (d.conv2_out,))
+    w["dense1_w"] = take("dense1_w", (d.conv2_out, d.dense1_out)); w["dense1_b"] = take("dense1_b", (d.dense1_out,))
+    w["dense2_w"] = take("dense2_w", (d.dense1_out, d.dense2_out)); w["dense2_b"] = take("dense2_b", (d.dense2_out,))
+    w["gru_a_dense_w"] = take("gru_a_dense_w", (d.dense2_out, 3 * na)); w["gru_a_dense_b"] = take("gru_a_dense_b", (3 * na,))
+    w["gru_b_dense_w"] = take("gru_b_dense_w", (d.dense2_out, 3 * nb)); w["gru_b_dense_b"] = take("gru_b_dense_b", (3 * nb,))
+    for key in ("embed_sig", "embed_pred", "embed_exc"):
+        w[key] = take(key, (256, 3 * na))
+    w["gru_a_rbias"] = take("gru_a_bias", (2, 3 * na))[1].copy()          # recurrent half (compute_sparse_gru)
+    w["gru_a_diag"] = take("gru_a_diag", (3 * na,))
+    cname = nm["gru_a_idx"]
+    if cname not in arrays:
+        raise ValueError(f"array '{cname}' (for gru_a_idx) not found")
+    idx = arrays[cname].astype(np.int32)
+    # walk the index list: 3 gates x N/8 row groups, each "count, positions..."
+    pos, nblocks = 0, 0
+    for _ in range(3 * na // 8):
+        if pos >= idx.size:
+            raise ValueError(f"array '{cname}' ends after {pos} entries: fewer than {3 * na // 8} row groups")
+        c = int(idx[pos])
+        if c < 0 or pos + 1 + c > idx.size or (idx[pos + 1:pos + 1 + c] % 4).any() or (idx[pos + 1:pos + 1 + c] >= na).any():
+            raise ValueError(f"array '{cname}': malformed row group at entry {pos}")
+        pos += 1 + c
+        nblocks += c
+    if pos != idx.size:
+        raise ValueError(f"array '{cname}' has {idx.size} entries, its row groups account for {pos}")
+    w["gru_a_idx"] = idx
+    w["gru_a_w"] = take("gru_a_w", (nblocks, 4, 8))
+    w["gru_b_bias"] = take("gru_b_bias", (2, 3 * nb))
+    w["gru_b_w_in"] = take("gru_b_w_in", (na, 3 * nb))
+    w["gru_b_w_rec"] = take("gru_b_w_rec", (nb, 3 * nb))
+    w["dual_fc_bias"] = take("dual_fc_bias", (2 * d.dual_fc_out,))
+    w["dual_fc_w"] = take("dual_fc_w", (d.dual_fc_out, 2, nb))
+    w["dual_fc_factor"] = take("dual_fc_factor", (2 * d.dual_fc_out,))
+    return w
+
+
+def convert(path_in: str, path_out: str, names: Optional[Dict[str, str]] = None) -> int:
+    with open(path_in, "r", errors="replace") as f:
+        w = weights_from_nnet_data(f.read(), names=names)
+    blob = pack_blob(w)
+    with open(path_out, "wb") as f:
+        f.write(blob)
+    return len(blob)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) != 3:
+        sys.exit("usage: python -m dss_amd.nnet_data <nnet_data.c> <out.blob>")
+    n = convert(sys.argv[1], sys.argv[2])
+    print(f"wrote {sys.argv[2]}: {n} bytes")
