@@ -1,4 +1,7 @@
 // Microbenchmark: cycles per dependent v_add_f32 / independent ops for one wave on a SIMD (gfx950).
+// SUPERSEDED by issue_rate.hip: every instruction here is an inline-asm statement, and the compiler puts an s_nop after
+// each of those, so the figures this prints (8.7 cycles per dependent add, ...) include a nop per instruction.  Kept
+// because DESIGN.md refers to the artefact.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
