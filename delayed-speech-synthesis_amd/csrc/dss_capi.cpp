@@ -435,6 +435,12 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         rc = dev_upload<float>(u2l, 256, &d); if (rc) return rc; m.ulaw2lin = d;
         rc = dev_upload<float>(dct, 324, &d); if (rc) return rc; m.dct_table = d;
         rc = dev_upload<float>(costab, 320, &d); if (rc) return rc; m.cos_table = d;
+        {
+            std::vector<float> ckl((size_t)160 * 17);
+            for (int k = 0; k < 160; ++k)
+                for (int lag = 0; lag < 17; ++lag) ckl[(size_t)k * 17 + lag] = costab[(k * lag) % 320];
+            rc = dev_upload<float>(ckl.data(), ckl.size(), &d); if (rc) return rc; m.cos_kl = d;
+        }
         rc = dev_upload<float>(ia, 160, &d); if (rc) return rc; m.interp_a = d;
         rc = dev_upload<float>(ib, 160, &d); if (rc) return rc; m.interp_b = d;
         rc = dev_upload<int>(iband, 160, &di); if (rc) return rc; m.interp_band = di;

@@ -65,6 +65,7 @@ struct DssModelDev {
     const float *ulaw2lin;        // [256]
     const float *dct_table;       // [18*18]
     const float *cos_table;       // [320]
+    const float *cos_kl;          // [160][17] cos_table[(bin * lag) mod 320]: the inverse-DFT factor of every (bin, lag)
     const float *interp_a, *interp_b;   // [160] (1-frac), frac of interp_band_gain
     const int *interp_band;       // [160] band index i of each bin
     const double *lag_window;     // [17] 1 - 6e-5*i*i

@@ -102,72 +102,93 @@ dense_rows_kernel(const float *__restrict__ x, long x_utt_stride, int x_row_stri
     }
 }
 
-// ---- lpc_from_cepstrum (freq.c) for every (utterance, frame): one wave per frame ------------------------
+// ---- lpc_from_cepstrum (freq.c) for every (utterance, frame): one lane per frame ------------------------------
+// Each lane runs the whole chain of its frame -- inverse DCT of the cepstrum, band interpolation, the 17 autocorrelation
+// lags as a direct inverse DFT (160 terms each, in ascending bin order), lag window, Levinson-Durbin -- with the
+// reference's operation order; the per-bin and per-(bin, lag) constants are wave-uniform (scalar loads), the
+// interpolated spectrum of a lane lives in LDS ([bin][lane], conflict-free).
 __constant__ float c_compensation[DSS_NB_BANDS] = {0.8f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.666667f, 0.5f, 0.5f, 0.5f,
                                                    0.333333f, 0.25f, 0.25f, 0.2f, 0.166667f, 0.173913f};
 
 __global__ void __launch_bounds__(64)
-frame_lpc_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, int n_frames, int feat_stride,
+frame_lpc_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, int total, int n_frames, int feat_stride,
                  double idct_scale)
 {
-    __shared__ float Ex[DSS_NB_BANDS];
-    __shared__ float Xr[161];
-    __shared__ float ac[DSS_LPC_ORDER + 1];
-    const int utt = blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
-    const float *cep = feat + ((size_t)utt * n_frames + t) * feat_stride;
-    if (lane < DSS_NB_BANDS) {
+    __shared__ float Xr[161][64];
+    constexpr int eband5ms[DSS_NB_BANDS] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40};
+    const int lane = threadIdx.x;
+    int gid = blockIdx.x * 64 + lane;
+    const bool valid = gid < total;
+    if (!valid) gid = total - 1;
+    const int utt = gid / n_frames, t = gid - utt * n_frames;
+    const float *cep = feat + (size_t)gid * feat_stride;
+    float c[DSS_NB_BANDS];
+#pragma unroll
+    for (int j = 0; j < DSS_NB_BANDS; ++j) c[j] = cep[j];
+    c[0] += 4;
+    float Ex[DSS_NB_BANDS];
+#pragma unroll
+    for (int i = 0; i < DSS_NB_BANDS; ++i) {
         float sum = 0;
-        for (int j = 0; j < DSS_NB_BANDS; ++j) {
-            float c = cep[j];
-            if (j == 0) c += 4;
-            sum += c * m.dct_table[lane * DSS_NB_BANDS + j];
-        }
+#pragma unroll
+        for (int j = 0; j < DSS_NB_BANDS; ++j) sum += c[j] * m.dct_table[i * DSS_NB_BANDS + j];
         const float e = (float)((double)sum * idct_scale);                 // sum*sqrt(2./NB_BANDS)
-        Ex[lane] = (float)(pow(10.0, (double)e) * (double)c_compensation[lane]);
+        Ex[i] = (float)(pow(10.0, (double)e) * (double)c_compensation[i]);
     }
-    __syncthreads();
-    for (int k = lane; k < 160; k += 64) {                                  // interp_band_gain
-        const int band = m.interp_band[k];
-        Xr[k] = m.interp_a[k] * Ex[band] + m.interp_b[k] * Ex[band + 1];
-    }
-    if (lane == 0) Xr[160] = 0.f;
-    __syncthreads();
-    if (lane <= DSS_LPC_ORDER) {                                            // direct inverse DFT, 17 lags
-        float acc = Xr[0];
-        int idx = 0;
-        for (int k = 1; k < 160; ++k) {
-            idx += lane;
-            if (idx >= 320) idx -= 320;
-            acc += (2.f * Xr[k]) * m.cos_table[idx];
+#pragma unroll
+    for (int i = 0; i < DSS_NB_BANDS - 1; ++i) {                            // interp_band_gain
+#pragma unroll
+        for (int j = 0; j < (eband5ms[i + 1] - eband5ms[i]) * 4; ++j) {
+            const int k = eband5ms[i] * 4 + j;
+            Xr[k][lane] = m.interp_a[k] * Ex[i] + m.interp_b[k] * Ex[i + 1];
         }
-        ac[lane] = acc;
     }
-    __syncthreads();
-    if (lane == 0) {
-        float a[DSS_LPC_ORDER + 1];
-        for (int i = 0; i <= DSS_LPC_ORDER; ++i) a[i] = ac[i];
-        a[0] = (float)((double)a[0] + ((double)a[0] * 1e-4 + 320 / 12 / 38.));
-        for (int i = 1; i <= DSS_LPC_ORDER; ++i) a[i] = (float)((double)a[i] * m.lag_window[i]);
-        float lpc[DSS_LPC_ORDER];
-        for (int i = 0; i < DSS_LPC_ORDER; ++i) lpc[i] = 0.f;
-        float error = a[0];
-        if (a[0] != 0) {
-            for (int i = 0; i < DSS_LPC_ORDER; i++) {
-                float rr = 0;
-                for (int j = 0; j < i; j++) rr += lpc[j] * a[i - j];
-                rr += a[i + 1];
-                const float r = -rr / error;
-                lpc[i] = r;
-                for (int j = 0; j < (i + 1) >> 1; j++) {
-                    const float tmp1 = lpc[j], tmp2 = lpc[i - 1 - j];
-                    lpc[j] = tmp1 + r * tmp2;
-                    lpc[i - 1 - j] = tmp2 + r * tmp1;
-                }
-                error = error - (r * r) * error;
-                if (error < .001f * a[0]) break;
+    Xr[160][lane] = 0.f;
+    float ac[DSS_LPC_ORDER + 1];
+    {
+        const float x0 = Xr[0][lane];
+#pragma unroll
+        for (int lag = 0; lag <= DSS_LPC_ORDER; ++lag) ac[lag] = x0;
+    }
+    for (int k = 1; k < 160; ++k) {                                         // direct inverse DFT, 17 lags, bins ascending
+        const float x2 = 2.f * Xr[k][lane];
+        const float *ck = m.cos_kl + k * (DSS_LPC_ORDER + 1);
+#pragma unroll
+        for (int lag = 0; lag <= DSS_LPC_ORDER; ++lag) ac[lag] += x2 * ck[lag];
+    }
+    float a[DSS_LPC_ORDER + 1];
+#pragma unroll
+    for (int i = 0; i <= DSS_LPC_ORDER; ++i) a[i] = ac[i];
+    a[0] = (float)((double)a[0] + ((double)a[0] * 1e-4 + 320 / 12 / 38.));
+#pragma unroll
+    for (int i = 1; i <= DSS_LPC_ORDER; ++i) a[i] = (float)((double)a[i] * m.lag_window[i]);
+    float lpc[DSS_LPC_ORDER];
+#pragma unroll
+    for (int i = 0; i < DSS_LPC_ORDER; ++i) lpc[i] = 0.f;
+    float error = a[0];
+    bool live = a[0] != 0;
+#pragma unroll
+    for (int i = 0; i < DSS_LPC_ORDER; i++) {
+        if (live) {
+            float rr = 0;
+#pragma unroll
+            for (int j = 0; j < i; j++) rr += lpc[j] * a[i - j];
+            rr += a[i + 1];
+            const float r = -rr / error;
+            lpc[i] = r;
+#pragma unroll
+            for (int j = 0; j < (i + 1) >> 1; j++) {
+                const float tmp1 = lpc[j], tmp2 = lpc[i - 1 - j];
+                lpc[j] = tmp1 + r * tmp2;
+                lpc[i - 1 - j] = tmp2 + r * tmp1;
             }
+            error = error - (r * r) * error;
+            if (error < .001f * a[0]) live = false;                          // the C loop's break
         }
+    }
+    if (valid) {
         float *dst = b.lpc_buf + ((size_t)utt * (n_frames + 2) + t + 2) * 16;
+#pragma unroll
         for (int i = 0; i < DSS_LPC_ORDER; ++i) dst[i] = lpc[i];
     }
 }
@@ -240,7 +261,8 @@ int dss_launch_frame_network(const DssModelDev &m, DssBatchDev &b, const float *
                                   b.frame_out, (long)F * DSS_COND_STRIDE, DSS_COND_STRIDE, 3 * DSS_GRU_A, F, rows, 0, b.fc0,
                                   m.tansig, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(frame_lpc_kernel, dim3(F, B), dim3(64), 0, s, m, b, d_features, F, feat_stride, sqrt(2. / DSS_NB_BANDS));
+    hipLaunchKernelGGL(frame_lpc_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, m, b, d_features, rows, F, feat_stride,
+                       sqrt(2. / DSS_NB_BANDS));
     DSS_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(frame_finish_kernel, dim3(F + 1, B), dim3(128), 0, s, b, F);
     DSS_HIP_CHECK(hipGetLastError());
