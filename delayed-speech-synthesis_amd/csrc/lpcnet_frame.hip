@@ -55,7 +55,10 @@ dense_rows_kernel(const float *__restrict__ x, long x_utt_stride, int x_row_stri
                   int rows_per_utt, int total_rows, int zero_below, const int *__restrict__ fc0,
                   const float *__restrict__ tansig)
 {
-    extern __shared__ __attribute__((aligned(16))) float xs[];     // [RT][M]
+    // the RT rows of the block, staged input-major ([input][row]): the products of one weight with two rows' inputs
+    // are then one packed multiply (v_pk_mul_f32, the weight broadcast to both halves); the sums stay one per product
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [M][RT]
+    static_assert(RT == 8, "staging and the packed products below are written for 8 rows per block");
     const int tid = threadIdx.x;
     const int i = blockIdx.y * 128 + tid;
     const int r0 = blockIdx.x * RT;
@@ -64,37 +67,39 @@ dense_rows_kernel(const float *__restrict__ x, long x_utt_stride, int x_row_stri
         if (r < total_rows) {
             const int ub = r / rows_per_utt, t = r - ub * rows_per_utt;
             const float *src = x + (size_t)ub * x_utt_stride + (size_t)t * x_row_stride;
-            for (int j = tid; j < M; j += 128) xs[rr * M + j] = src[j];
+            for (int j = tid; j < M; j += 128) xs[j * RT + rr] = src[j];
         } else {
-            for (int j = tid; j < M; j += 128) xs[rr * M + j] = 0.f;
+            for (int j = tid; j < M; j += 128) xs[j * RT + rr] = 0.f;
         }
     }
     __syncthreads();
     if (i >= N) return;
-    float acc[RT];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x2 acc[RT / 2];
     const float bi = bias[i];
 #pragma unroll
-    for (int rr = 0; rr < RT; ++rr) acc[rr] = bi;
-    for (int j = 0; j < M; j += 4) {
+    for (int p = 0; p < RT / 2; ++p) acc[p] = (f32x2){bi, bi};
+    for (int j = 0; j < M; j += 2) {
         const float w0 = W[(size_t)(j + 0) * N + i];
         const float w1 = W[(size_t)(j + 1) * N + i];
-        const float w2 = W[(size_t)(j + 2) * N + i];
-        const float w3 = W[(size_t)(j + 3) * N + i];
-#pragma unroll
-        for (int rr = 0; rr < RT; ++rr) {
-            const float4 xv = *reinterpret_cast<const float4 *>(&xs[rr * M + j]);
-            acc[rr] += w0 * xv.x;
-            acc[rr] += w1 * xv.y;
-            acc[rr] += w2 * xv.z;
-            acc[rr] += w3 * xv.w;
-        }
+        const f32x4 xa = *reinterpret_cast<const f32x4 *>(&xs[(j + 0) * RT]), xb = *reinterpret_cast<const f32x4 *>(&xs[(j + 0) * RT + 4]);
+        const f32x4 xc = *reinterpret_cast<const f32x4 *>(&xs[(j + 1) * RT]), xd = *reinterpret_cast<const f32x4 *>(&xs[(j + 1) * RT + 4]);
+        // products first (a packed result needs a wait state before it can be read), then the sums: per row still
+        // "acc += w[j]*x[j]" in ascending j, each product and each sum rounded on its own (xiph sgemv_accum)
+        const f32x2 p0 = (f32x2){w0, w0} * xa.lo, p1 = (f32x2){w0, w0} * xa.hi, p2 = (f32x2){w0, w0} * xb.lo, p3 = (f32x2){w0, w0} * xb.hi;
+        const f32x2 q0 = (f32x2){w1, w1} * xc.lo, q1 = (f32x2){w1, w1} * xc.hi, q2 = (f32x2){w1, w1} * xd.lo, q3 = (f32x2){w1, w1} * xd.hi;
+        acc[0].x += p0.x; acc[0].y += p0.y; acc[1].x += p1.x; acc[1].y += p1.y;
+        acc[2].x += p2.x; acc[2].y += p2.y; acc[3].x += p3.x; acc[3].y += p3.y;
+        acc[0].x += q0.x; acc[0].y += q0.y; acc[1].x += q1.x; acc[1].y += q1.y;
+        acc[2].x += q2.x; acc[2].y += q2.y; acc[3].x += q3.x; acc[3].y += q3.y;
     }
 #pragma unroll
     for (int rr = 0; rr < RT; ++rr) {
         const int r = r0 + rr;
         if (r < total_rows) {
             const int ub = r / rows_per_utt, t = r - ub * rows_per_utt;
-            float v = acc[rr];
+            float v = (rr & 1) ? acc[rr / 2].y : acc[rr / 2].x;
             if (ACT == ACT_TANH) v = dss_tanh_approx(tansig, v);
             if (zero_below > 0 && fc0[ub] + t < zero_below) v = 0.f;   // lpcnet.c: RNN_CLEAR while frame_count < delay
             out[(size_t)ub * out_utt_stride + (size_t)t * out_row_stride + out_col_off + i] = v;
