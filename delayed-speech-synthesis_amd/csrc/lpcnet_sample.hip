@@ -265,6 +265,19 @@ struct SampleLds {
             : "scc");                                                                            \
     }
 
+// one candidate excitation value of the speculation, for wave 6 (inputs published by wave 7 right after its tree walk)
+#define DSS_SPECULATE(CAND)                                                                      \
+    {                                                                                            \
+        const int cand_ = (CAND);                                                                \
+        const float pcm_c = L.spec_pred + L.ulaw2lin[cand_];                                     \
+        float pc = 0;                                                                            \
+        pc -= pcm_c * L.spec_lpc[0];                                                             \
+        _Pragma("unroll") for (int j = 1; j < DSS_LPC_ORDER; ++j) pc -= L.spec_ls[j - 1] * L.spec_lpc[j]; \
+        const int su_c = dss_lin2ulaw(pcm_c), pu_c = dss_lin2ulaw(pc);                           \
+        L.spec_tab_pred[cand_] = pc;                                                             \
+        L.spec_tab_idx[cand_] = (unsigned short)(su_c | (pu_c << 8));                            \
+    }
+
 // wave 7: fold the sampled excitation into the signal history and emit the PCM sample (lpcnet_synthesize_tail_impl)
 #define DSS_S_UPDATE()                                                                           \
     {                                                                                            \
@@ -418,10 +431,10 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
             DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
             DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
-            if (wave >= 4 || wave < 2) {
-                // Speculation over all 256 possible excitation values of THIS sample, one candidate per lane of waves 4, 5
-                // (candidates 0..127) and of waves 0, 1, which have the lightest B..C load of the dual-FC waves
-                // (128..255): the next sample's LPC prediction and mu-law indices, so that once the tree walk has
+            if (wave == 5 || wave < 2) {
+                // Speculation over all 256 possible excitation values of THIS sample, one candidate per lane of wave 5
+                // (candidates 64..127), of waves 0, 1, which have the lightest B..C load of the dual-FC waves (128..255),
+                // and of wave 6 once it has handed its half of the GRU B chain over (0..63): the next sample's LPC prediction and mu-law indices, so that once the tree walk has
                 // picked the value nobody has to run the two ~40-step dependent chains.  Same expressions, same order
                 // as lpcnet_synthesize_tail_impl().
                 const int cand = HAS_FC ? 128 + tid : tid - 256;
@@ -541,6 +554,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 DSS_GB_CHAIN(an, GBH6)
                 L.gb_acc[lane] = acc;
                 __hip_atomic_store(&L.gb_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                DSS_SPECULATE(lane)                          // this wave is idle from here to barrier B: candidates 0..63
                 __syncthreads();                                                        // barrier C
                 __syncthreads();                                                        // barrier D
                 cur ^= 1;
@@ -624,6 +638,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 float rec = gbb1;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) rec += L.gb_wrec[j * NB3 + row] * L.state_b[j];
+                const float sb_old = L.state_b[lane & (NB - 1)];     // the h lanes' own unit: read here, not after the chain
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[2] += t - t_prev; t_prev = t; }
                 // While wave 6 runs the first half of the chain, this wave forms the products of its first GBP inputs (it
@@ -693,10 +708,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     const float z_for_h = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(0u, zb, false, false)[0]);      // 32..47 <- 0..15
                     float hh = acc + rec * r_for_h;
                     hh = dss_tanh_approx(L.tansig, hh);
-                    if (lane >= 2 * NB && lane < NB3) {
-                        const float sb = L.state_b[lane - 2 * NB];
-                        L.state_b[lane - 2 * NB] = z_for_h * sb + (1 - z_for_h) * hh;
-                    }
+                    if (lane >= 2 * NB && lane < NB3) L.state_b[lane - 2 * NB] = z_for_h * sb_old + (1 - z_for_h) * hh;
                 }
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
