@@ -158,26 +158,58 @@ hga_filter_kernel(const double *__restrict__ data, double *__restrict__ zi, doub
     }
 }
 
-// ---- stage 2: windowed mean power, one lane per (stream, window, channel) -----------------------------------------
+// ---- stage 2: windowed mean power ---------------------------------------------------------------------------------
+// A 256-thread block takes 8 consecutive windows x 32 consecutive channels of one stream: the rows those windows cover
+// (50 + 7*10 for the reference's 50 ms / 10 ms at 1 kHz) are staged once through LDS in 256-byte row segments instead
+// of being fetched by each of the five windows that overlap them; lane (window, channel) then runs its window's
+// sequential sum over rows exactly as array_sum_and_power does (pyx:9-22).
+#define HGA_WB 8
+#define HGA_WC 32
+#define HGA_WROWS 160            // LDS rows per block; a block whose windows span more falls back to global reads
+
 __global__ void __launch_bounds__(256)
 hga_window_kernel(const double *__restrict__ rowbuf, double *__restrict__ out, int S, int C, int W, int cap_rows, int sr,
                   float wl, float ws, int apply_log)
 {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)S * W * C) return;
-    const int c = (int)(gid % C);
-    const int win = (int)((gid / C) % W);
-    const int s = (int)(gid / ((long)C * W));
-    const double *col = rowbuf + (size_t)s * cap_rows * C + c;
+    __shared__ double tile[HGA_WROWS][HGA_WC];
+    const int tid = threadIdx.x, cl = tid & (HGA_WC - 1), wi = tid / HGA_WC;
+    const int cgroups = (C + HGA_WC - 1) / HGA_WC, wchunks = (W + HGA_WB - 1) / HGA_WB;
+    int bid = blockIdx.x;
+    const int wc = bid % wchunks; bid /= wchunks;
+    const int cg = bid % cgroups;
+    const int s = bid / cgroups;
+    const int w0 = wc * HGA_WB, wlast = min(w0 + HGA_WB, W) - 1;
+    const int row_lo = hga_win_start(w0, ws, sr);
+    const int row_hi = hga_win_stop(hga_win_start(wlast, ws, sr), wl, sr);
+    const int nrows = row_hi - row_lo;
+    const bool staged = nrows <= HGA_WROWS;
+    const double *base = rowbuf + (size_t)s * cap_rows * C;
+    const int c0 = cg * HGA_WC;
+    if (staged) {
+        for (int idx = tid; idx < nrows * HGA_WC; idx += 256) {
+            const int rr = idx / HGA_WC, cc = idx - rr * HGA_WC;
+            tile[rr][cc] = (c0 + cc < C) ? base[(size_t)(row_lo + rr) * C + c0 + cc] : 0.0;
+        }
+    }
+    __syncthreads();
+    const int win = w0 + wi, c = c0 + cl;
+    if (win >= W || c >= C) return;
     const int start = hga_win_start(win, ws, sr);
     const int stop = hga_win_stop(start, wl, sr);
     double sum = 0.0;
-    for (int rr = start; rr < stop; ++rr) {                // array_sum_and_power, pyx:9-22: sequential over rows
-        const double v = col[(size_t)rr * C];
-        sum += v * v;
+    if (staged) {
+        for (int rr = start; rr < stop; ++rr) {
+            const double v = tile[rr - row_lo][cl];
+            sum += v * v;
+        }
+    } else {
+        for (int rr = start; rr < stop; ++rr) {
+            const double v = base[(size_t)rr * C + c];
+            sum += v * v;
+        }
     }
     const double p = sum / (double)(stop - start) + 0.01;
-    out[gid] = apply_log ? log(p) : p;
+    out[((size_t)s * W + win) * C + c] = apply_log ? log(p) : p;
 }
 
 // ---- stage 3: keep the last `overlap` rows (ascending copy: a source row is always ahead of its destination) ------
@@ -201,9 +233,9 @@ int dss_launch_hga(const DssHgaDev &h, const double *d_data, int n, int row0, in
                        h.S, h.C, n, h.nsec, row0, h.cap_rows, zero_rows);
     DSS_HIP_CHECK(hipGetLastError());
     if (W > 0) {
-        const long total = pairs * W;
-        hipLaunchKernelGGL(hga_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h.rows, d_out, h.S,
-                           h.C, W, h.cap_rows, h.fs, h.wl, h.ws, apply_log);
+        const long blocks = (long)h.S * ((h.C + HGA_WC - 1) / HGA_WC) * ((W + HGA_WB - 1) / HGA_WB);
+        hipLaunchKernelGGL(hga_window_kernel, dim3((unsigned)blocks), dim3(256), 0, st, h.rows, d_out, h.S, h.C, W, h.cap_rows,
+                           h.fs, h.wl, h.ws, apply_log);
         DSS_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(hga_overlap_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, h.rows, h.S, h.C,
