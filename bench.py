@@ -166,7 +166,7 @@ def main():
     traffic = None
     try:
         if B == 256:
-            with open(os.path.join(ROOT, "profiles", "r1h_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r1i_pmc_traffic.json")) as f:
                 traffic = float(json.load(f)["hbm_bytes_per_launch_corrected"]) / 1e9      # GB per launch
     except Exception:
         traffic = None
