@@ -249,3 +249,20 @@ def test_long_utterance_and_extreme_features(oracle, model):
     dec = oracle.decoder(model)
     want_edge = np.concatenate([dec.synthesize(edge[t]) for t in range(40)])
     assert np.array_equal(got_edge, want_edge)
+
+
+def test_config4_per_gpu_share_1024_utterances(golden, model):
+    """BASELINE.json configs[3] per GPU: 1024 utterances of 1 s in one call (four rounds of workgroups).  Size-independent
+    properties: identical inputs give identical PCM wherever they sit in the batch, and the two golden utterances come
+    out bit-exact from the first and the last round."""
+    from dss_amd.lpcnet import LPCNetBatch
+    g = golden("lpcnet_self.npz")
+    B, F = 1024, 100
+    f0, f1 = synthetic_features(0, F), synthetic_features(1, F)
+    feats = np.empty((B, F, 20), dtype=np.float32)
+    feats[0::2] = f0
+    feats[1::2] = f1
+    pcm = LPCNetBatch(B, F).synthesize(feats)
+    assert np.array_equal(pcm[0], g["utt0_pcm"]) and np.array_equal(pcm[1], g["utt1_pcm"])
+    assert np.array_equal(pcm[1022], g["utt0_pcm"]) and np.array_equal(pcm[1023], g["utt1_pcm"])
+    assert (pcm[0::2] == pcm[0]).all() and (pcm[1::2] == pcm[1]).all()
