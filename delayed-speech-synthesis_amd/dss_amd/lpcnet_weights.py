@@ -64,9 +64,17 @@ def _shapes(d: LPCNetDims, nblocks: int, idx_len: int) -> Dict[str, tuple]:
     }
 
 
+GRUA_INPUT_FIRST, GRUA_RECUR_FIRST = 0, 1      # dss_blob_header.gru_a_order
+
+
 def make_synthetic_weights(seed: int = 0, dims: LPCNetDims = LPCNetDims(),
-                           density=(0.05, 0.05, 0.20)) -> Dict[str, np.ndarray]:
-    """Seeded random model of the published LPCNet decoder architecture."""
+                           density=(0.05, 0.05, 0.20), skew: float = 0.0) -> Dict[str, np.ndarray]:
+    """Seeded random model of the published LPCNet decoder architecture.
+
+    ``skew`` = 0 places the kept 8x4 blocks uniformly at random (every row group has about the same count).
+    ``skew`` > 0 imitates what xiph's training does (magnitude pruning keeps the top-k blocks of a gate
+    GLOBALLY, so some row groups keep many more blocks than others): each row group draws a log-normal
+    "importance" with that sigma and the kept blocks are the top-k of importance x per-block noise."""
     d = dims
     rng = np.random.default_rng(seed)
     f32 = np.float32
@@ -101,7 +109,11 @@ def make_synthetic_weights(seed: int = 0, dims: LPCNetDims = LPCNetDims(),
     blocks = []
     for g, dens in enumerate(density):
         n_keep = int(round(dens * groups_per_gate * col_blocks))
-        keep = rng.choice(groups_per_gate * col_blocks, size=n_keep, replace=False)
+        if skew > 0:
+            score = np.exp(skew * rng.standard_normal((groups_per_gate, 1))) * rng.random((groups_per_gate, col_blocks))
+            keep = np.argsort(-score.ravel(), kind="stable")[:n_keep]
+        else:
+            keep = rng.choice(groups_per_gate * col_blocks, size=n_keep, replace=False)
         mask = np.zeros(groups_per_gate * col_blocks, dtype=bool)
         mask[keep] = True
         mask = mask.reshape(groups_per_gate, col_blocks)
@@ -142,14 +154,16 @@ def make_synthetic_weights(seed: int = 0, dims: LPCNetDims = LPCNetDims(),
     return w
 
 
-def pack_blob(w: Dict[str, np.ndarray], dims: LPCNetDims = LPCNetDims()) -> bytes:
+def pack_blob(w: Dict[str, np.ndarray], dims: LPCNetDims = LPCNetDims(), gru_a_order: int = GRUA_INPUT_FIRST) -> bytes:
     d = dims
+    if gru_a_order not in (GRUA_INPUT_FIRST, GRUA_RECUR_FIRST):
+        raise ValueError("gru_a_order must be 0 (input first, xiph 2021) or 1 (recurrent first, xiph 2019-2020)")
     nblocks = int(w["gru_a_w"].shape[0])
     idx_len = int(w["gru_a_idx"].shape[0])
     shapes = _shapes(d, nblocks, idx_len)
     header = struct.pack(
         "<8s22i", MAGIC, 1, d.nb_features, d.nb_bands, d.embed_pitch_dim, d.pitch_max, d.conv1_out, d.conv2_out,
-        d.dense1_out, d.dense2_out, d.gru_a, d.gru_b, d.dual_fc_out, d.lpc_order, nblocks, idx_len, 0, 0, 0, 0, 0, 0, 0)
+        d.dense1_out, d.dense2_out, d.gru_a, d.gru_b, d.dual_fc_out, d.lpc_order, nblocks, idx_len, int(gru_a_order), 0, 0, 0, 0, 0, 0)
     assert len(header) == 96
     parts = [header]
     for name in _SECTIONS:
@@ -182,14 +196,20 @@ def unpack_blob(blob: bytes):
     return dims, w
 
 
-_cache: Dict[int, bytes] = {}
+def blob_gru_a_order(blob: bytes) -> int:
+    return struct.unpack_from("<i", blob, 8 + 4 * 15)[0]
 
 
-def synthetic_blob(seed: int = 0) -> bytes:
-    """Blob of the default synthetic model (cached per process)."""
-    if seed not in _cache:
-        _cache[seed] = pack_blob(make_synthetic_weights(seed))
-    return _cache[seed]
+_cache: Dict[tuple, bytes] = {}
+
+
+def synthetic_blob(seed: int = 0, gru_a_order: int = GRUA_INPUT_FIRST, skew: float = 0.0) -> bytes:
+    """Blob of a synthetic model (cached per process).  TESTS AND BENCHMARKS ONLY: random weights make noise,
+    not speech."""
+    key = (seed, gru_a_order, skew)
+    if key not in _cache:
+        _cache[key] = pack_blob(make_synthetic_weights(seed, skew=skew), gru_a_order=gru_a_order)
+    return _cache[key]
 
 
 def algorithmic_bytes_per_sample(blob: bytes) -> float:

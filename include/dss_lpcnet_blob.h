@@ -57,7 +57,18 @@ typedef struct dss_blob_header {
     int32_t lpc_order;        /* 16 */
     int32_t sparse_nblocks;   /* number of 8x4 blocks in gru_a_w */
     int32_t sparse_idx_len;   /* number of int32 in gru_a_idx */
-    int32_t reserved[7];
+    int32_t gru_a_order;      /* association order of the z/r pre-activations of compute_sparse_gru:
+                               *   DSS_GRUA_INPUT_FIRST (0)  ((bias + diag*state) + input) + blocks...   xiph nnet.c since the
+                               *                             8x4-block / int8 rewrite (early 2021), the era of the reference's
+                               *                             TU list (extensions/lpcnet/setup.py:34-36)
+                               *   DSS_GRUA_RECUR_FIRST (1)  input + ((bias + diag*state) + blocks...)    xiph nnet.c 2019-2020
+                               *                             (zrh = input; recur = bias + diag*state + sparse; zrh += recur)
+                               * The h gate is the same in both (r*recur_h + input_h; a float add commutes).  Blobs written
+                               * before this field existed have 0 here. */
+    int32_t reserved[6];
 } dss_blob_header;            /* 96 bytes */
+
+#define DSS_GRUA_INPUT_FIRST 0
+#define DSS_GRUA_RECUR_FIRST 1
 
 #endif

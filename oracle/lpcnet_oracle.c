@@ -19,8 +19,17 @@
  *   - lpc_from_cepstrum's 320-point inverse FFT (kiss_fft) is restated as the direct real inverse
  *     DFT of the 17 lags Levinson needs -- equal in exact arithmetic, not bit-for-bit with kiss_fft;
  *   - tanh/sigmoid use the 201-entry table form (tansig_table[i] = tanh(0.04 i) to 6 decimals).
- * What pins this file today: oracle-vs-HIP bit equality and the committed self-generated golden
- * vectors (tests/golden/lpcnet_*.npz).  The +-1 LSB claim against real xiph C stays open.
+ * What pins this file today (tests/test_oracle_lpcnet_pins.py; DESIGN.md section 2 lists every assumption
+ * with the test that covers it): Marsaglia's published KISS99 check values, the mu-law round trip over
+ * all 256 codes, lpc_from_cepstrum against numpy's 320-point inverse FFT + scipy's Toeplitz solver,
+ * Levinson on closed-form autocorrelations, the activation tables against libm, and an independent
+ * NumPy restatement of one sample step written from the layer definitions (teacher-forced, all 255
+ * node logits); plus oracle-vs-HIP bit equality and the committed self-generated golden vectors
+ * (tests/golden/lpcnet_*.npz).  None of these is an output of xiph's own code: the +-1 LSB claim
+ * against real xiph C stays open, and tests/golden/lpcnet_xiph.npz is the slot that closes it.
+ *
+ * The association order of compute_sparse_gru's z/r pre-activations differs between public xiph
+ * revisions; both are implemented and the blob header selects one (dss_blob_header.gru_a_order).
  *
  * Float discipline: every operation below is IEEE binary32 (or binary64 where the xiph source
  * promotes to double), evaluated in source order, no FMA contraction (build: -O2 -ffp-contract=off,
@@ -112,6 +121,10 @@ static int lin2ulaw(float x)         /* xiph common.h */
     return (int)floor(.5 + u);
 }
 
+/* exported for the known-answer tests */
+int oracle_lin2ulaw(float x) { return lin2ulaw(x); }
+float oracle_ulaw2lin(float u) { return ulaw2lin(u); }
+
 oracle_lpcnet_model *oracle_lpcnet_model_load(const void *blob, size_t len)
 {
     if (len < sizeof(dss_blob_header)) return NULL;
@@ -120,6 +133,7 @@ oracle_lpcnet_model *oracle_lpcnet_model_load(const void *blob, size_t len)
     if (memcmp(m->h.magic, DSS_BLOB_MAGIC, 8) != 0 || m->h.version != 1) { free(m); return NULL; }
     const dss_blob_header *h = &m->h;
     if (h->nb_bands != NB_BANDS || h->lpc_order != LPC_ORDER || 3 * h->gru_a > MAX_N) { free(m); return NULL; }
+    if (h->gru_a_order != DSS_GRUA_INPUT_FIRST && h->gru_a_order != DSS_GRUA_RECUR_FIRST) { free(m); return NULL; }
     m->storage = malloc(len);
     memcpy(m->storage, blob, len);
     const float *p = (const float *)((const char *)m->storage + sizeof(dss_blob_header));
@@ -206,6 +220,9 @@ static float sigmoid_approx(const oracle_lpcnet_model *m, float x)
     return .5f + .5f * tanh_approx(m, .5f * x);
 }
 
+float oracle_tanh_approx(const oracle_lpcnet_model *m, float x) { return tanh_approx(m, x); }
+float oracle_sigmoid_approx(const oracle_lpcnet_model *m, float x) { return sigmoid_approx(m, x); }
+
 /* sgemv_accum (vec.h generic): out[i] += w[j*stride + i] * x[j], j ascending, one product at a time */
 static void sgemv_accum(float *out, const float *w, int rows, int cols, int stride, const float *x)
 {
@@ -272,6 +289,28 @@ static void kiss99_srand(kiss99_ctx *c, const unsigned char *data, int n)
     if (c->jsr == 0) c->jsr++;
 }
 
+/* exported for the known-answer tests (Marsaglia's check values, the "LPCNet" seeding) */
+void oracle_kiss99_seed(uint32_t *ctx4, uint32_t z, uint32_t w, uint32_t jsr, uint32_t jcong)
+{
+    ctx4[0] = z; ctx4[1] = w; ctx4[2] = jsr; ctx4[3] = jcong;
+}
+void oracle_kiss99_srand(uint32_t *ctx4, const unsigned char *data, int n)
+{
+    kiss99_ctx c;
+    kiss99_srand(&c, data, n);
+    ctx4[0] = c.z; ctx4[1] = c.w; ctx4[2] = c.jsr; ctx4[3] = c.jcong;
+}
+/* n draws; the last min(n, n_keep) values are stored in out (oldest first) */
+void oracle_kiss99_draw(uint32_t *ctx4, long n, uint32_t *out, long n_keep)
+{
+    kiss99_ctx c = {ctx4[0], ctx4[1], ctx4[2], ctx4[3]};
+    for (long i = 0; i < n; ++i) {
+        uint32_t v = kiss99_rand(&c);
+        if (out && i >= n - n_keep) out[i - (n - n_keep)] = v;
+    }
+    ctx4[0] = c.z; ctx4[1] = c.w; ctx4[2] = c.jsr; ctx4[3] = c.jcong;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * decoder state (lpcnet_private.h LPCNetState)
  * ---------------------------------------------------------------------------------------------- */
@@ -294,14 +333,22 @@ typedef struct {
     unsigned char *trace_exc;
     float *trace_pcm;       /* pred + ulaw2lin(exc), before de-emphasis */
     long trace_pos, trace_cap;
+    /* optional teacher forcing (tests): the excitation index of sample k is taken from forced_exc[k]
+     * instead of the sampled one (the RNG still advances, so a free-running continuation stays aligned),
+     * and the pre-threshold logits of ALL 255 tree nodes of sample k go to forced_logits[k*256 + node] */
+    const unsigned char *forced_exc;
+    float *forced_logits;
+    long forced_pos, forced_cap;
 } oracle_lpcnet_state;
 
 int oracle_lpcnet_init(oracle_lpcnet_state *st)
 {
     const oracle_lpcnet_model *m = st->m;
     unsigned char *te = st->trace_exc; float *tp = st->trace_pcm; long cap = st->trace_cap;
+    const unsigned char *fe = st->forced_exc; float *fl = st->forced_logits; long fcap = st->forced_cap;
     memset(st, 0, sizeof(*st));
     st->m = m; st->trace_exc = te; st->trace_pcm = tp; st->trace_cap = cap;
+    st->forced_exc = fe; st->forced_logits = fl; st->forced_cap = fcap;
     st->last_exc = lin2ulaw(0.f);
     kiss99_srand(&st->rng, (const unsigned char *)"LPCNet", 6);
     return 0;
@@ -321,6 +368,22 @@ void oracle_lpcnet_destroy(oracle_lpcnet_state *st) { free(st); }
 void oracle_lpcnet_set_trace(oracle_lpcnet_state *st, unsigned char *exc, float *pcm, long cap)
 {
     st->trace_exc = exc; st->trace_pcm = pcm; st->trace_cap = cap; st->trace_pos = 0;
+}
+
+void oracle_lpcnet_set_forced(oracle_lpcnet_state *st, const unsigned char *exc, float *logits, long cap)
+{
+    st->forced_exc = exc; st->forced_logits = logits; st->forced_cap = cap; st->forced_pos = 0;
+}
+
+/* test hook: overwrite the recurrent state and the per-frame conditioning (teacher-forced single steps) */
+void oracle_lpcnet_set_state(oracle_lpcnet_state *st, const float *gru_a_state, const float *gru_b_state,
+                             const float *cond_a, const float *cond_b)
+{
+    const int N = st->m->h.gru_a, NB = st->m->h.gru_b;
+    if (gru_a_state) memcpy(st->gru_a_state, gru_a_state, sizeof(float) * N);
+    if (gru_b_state) memcpy(st->gru_b_state, gru_b_state, sizeof(float) * NB);
+    if (cond_a) memcpy(st->gru_a_condition, cond_a, sizeof(float) * 3 * N);
+    if (cond_b) memcpy(st->gru_b_condition, cond_b, sizeof(float) * 3 * NB);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -349,6 +412,8 @@ static float celt_lpc(float *lpc, const float *ac, int p)      /* celt_lpc.c _ce
     }
     return error;
 }
+
+float oracle_celt_lpc(float *lpc, const float *ac, int p) { return celt_lpc(lpc, ac, p); }
 
 void oracle_lpc_from_cepstrum(const oracle_lpcnet_model *m, float *lpc, const float *cepstrum)
 {
@@ -430,9 +495,12 @@ static int run_sample_network(oracle_lpcnet_state *st, int last_exc, int last_si
         float *state = st->gru_a_state;
         float *z = recur, *r = recur + N, *hh = recur + 2 * N;
         int k;
+        const int recur_first = m->h.gru_a_order == DSS_GRUA_RECUR_FIRST;
         for (k = 0; k < 2; k++)
-            for (int i = 0; i < N; i++)
-                recur[k * N + i] = m->gru_a_rbias[k * N + i] + m->gru_a_diag[k * N + i] * state[i] + gru_a_input[k * N + i];
+            for (int i = 0; i < N; i++) {
+                recur[k * N + i] = m->gru_a_rbias[k * N + i] + m->gru_a_diag[k * N + i] * state[i];
+                if (!recur_first) recur[k * N + i] = recur[k * N + i] + gru_a_input[k * N + i];   /* nnet.c 2021: input first */
+            }
         for (; k < 3; k++)
             for (int i = 0; i < N; i++)
                 recur[k * N + i] = m->gru_a_rbias[k * N + i] + m->gru_a_diag[k * N + i] * state[i];
@@ -451,6 +519,8 @@ static int run_sample_network(oracle_lpcnet_state *st, int last_exc, int last_si
                 w += 32;
             }
         }
+        if (recur_first)                                     /* nnet.c 2019-2020: zrh = input; zrh += recur */
+            for (int i = 0; i < 2 * N; i++) recur[i] = gru_a_input[i] + recur[i];
         for (int i = 0; i < 2 * N; i++) recur[i] = sigmoid_approx(m, recur[i]);
         for (int i = 0; i < N; i++) hh[i] = hh[i] * r[i] + gru_a_input[2 * N + i];
         for (int i = 0; i < N; i++) hh[i] = tanh_approx(m, hh[i]);
@@ -486,22 +556,52 @@ static int run_sample_network(oracle_lpcnet_state *st, int last_exc, int last_si
             thresholds[b + 2] = m->sampling_logit_table[(r >> 16) & 0xFF];
             thresholds[b + 3] = m->sampling_logit_table[(r >> 24) & 0xFF];
         }
+#define NODE_LOGIT(i, out) do {                                                             \
+            float s1_ = m->dual_fc_bias[i];                                                \
+            float s2_ = m->dual_fc_bias[(i) + Nout];                                       \
+            for (int j = 0; j < M; j++) {                                                   \
+                s1_ += m->dual_fc_w[(i) * stride + j] * st->gru_b_state[j];                \
+                s2_ += m->dual_fc_w[(i) * stride + j + M] * st->gru_b_state[j];            \
+            }                                                                               \
+            s1_ = m->dual_fc_factor[i] * tanh_approx(m, s1_);                             \
+            s2_ = m->dual_fc_factor[Nout + (i)] * tanh_approx(m, s2_);                    \
+            s1_ += s2_;                                                                   \
+            (out) = s1_;                                                                   \
+        } while (0)
         for (int b = 0; b < 8; b++) {
             int i = (1 << b) | val;
-            float sum1 = m->dual_fc_bias[i];
-            float sum2 = m->dual_fc_bias[i + Nout];
-            for (int j = 0; j < M; j++) {
-                sum1 += m->dual_fc_w[i * stride + j] * st->gru_b_state[j];
-                sum2 += m->dual_fc_w[i * stride + j + M] * st->gru_b_state[j];
-            }
-            sum1 = m->dual_fc_factor[i] * tanh_approx(m, sum1);
-            sum2 = m->dual_fc_factor[Nout + i] * tanh_approx(m, sum2);
-            sum1 += sum2;
+            float sum1;
+            NODE_LOGIT(i, sum1);
             int bit = thresholds[b] < sum1;
             val = (val << 1) | bit;
         }
+        if (st->forced_exc && st->forced_pos < st->forced_cap) {     /* teacher forcing (tests only) */
+            if (st->forced_logits) {
+                float *lo = st->forced_logits + st->forced_pos * 256;
+                lo[0] = 0.f;
+                for (int i = 1; i < Nout; i++) NODE_LOGIT(i, lo[i]);
+            }
+            val = st->forced_exc[st->forced_pos++];
+        }
+#undef NODE_LOGIT
         return val;
     }
+}
+
+/* test hook: ONE run_sample_network step on the current state with the three embedding indices given;
+ * returns the sampled excitation (the RNG advances as in synthesis) and, when logits256 != NULL, the
+ * pre-threshold logits of all 255 tree nodes (index = node, [0] unused). */
+int oracle_lpcnet_sample_step(oracle_lpcnet_state *st, int last_exc, int last_sig_ulaw, int pred_ulaw, float *logits256)
+{
+    const unsigned char *fe = st->forced_exc; float *fl = st->forced_logits; long fp = st->forced_pos, fc = st->forced_cap;
+    unsigned char sink = 0;
+    int exc;
+    if (logits256) { st->forced_exc = &sink; st->forced_logits = logits256; st->forced_pos = 0; st->forced_cap = 1; }
+    else st->forced_exc = NULL;
+    /* with logits requested the walk's own result is replaced by `sink`; redo the walk from the logits */
+    exc = run_sample_network(st, last_exc, last_sig_ulaw, pred_ulaw);
+    st->forced_exc = fe; st->forced_logits = fl; st->forced_pos = fp; st->forced_cap = fc;
+    return exc;
 }
 
 /* lpcnet.c: lpcnet_synthesize = run_frame_network + lpcnet_synthesize_tail_impl(preload = 0) */

@@ -43,6 +43,22 @@ class Oracle:
         L.oracle_lpcnet_tap.restype = C.POINTER(C.c_float)
         L.oracle_lpcnet_tap.argtypes = [C.c_void_p, C.c_int]
         L.oracle_lpc_from_cepstrum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_lin2ulaw.restype = C.c_int
+        L.oracle_lin2ulaw.argtypes = [C.c_float]
+        L.oracle_ulaw2lin.restype = C.c_float
+        L.oracle_ulaw2lin.argtypes = [C.c_float]
+        for f in (L.oracle_tanh_approx, L.oracle_sigmoid_approx):
+            f.restype = C.c_float
+            f.argtypes = [C.c_void_p, C.c_float]
+        L.oracle_kiss99_seed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_kiss99_srand.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.oracle_kiss99_draw.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        L.oracle_celt_lpc.restype = C.c_float
+        L.oracle_celt_lpc.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_lpcnet_set_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        L.oracle_lpcnet_sample_step.restype = C.c_int
+        L.oracle_lpcnet_sample_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_lpcnet_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 
     # ---- HGA ---------------------------------------------------------------------------------
     def sosfilt(self, sos, x, zi):
@@ -131,6 +147,23 @@ class Oracle:
                 self.trace_pcm = np.zeros(trace_cap, np.float32)
                 lib.oracle_lpcnet_set_trace(self.h, _p(self.trace_exc), _p(self.trace_pcm), trace_cap)
 
+        def force(self, exc, want_logits=True):
+            """Teacher forcing: sample k takes exc[k]; all 255 node logits of each forced sample are recorded."""
+            self.forced_exc = np.ascontiguousarray(exc, dtype=np.uint8)
+            self.forced_logits = np.zeros((len(self.forced_exc), 256), np.float32) if want_logits else None
+            self.lib.oracle_lpcnet_set_forced(self.h, _p(self.forced_exc),
+                                              _p(self.forced_logits) if want_logits else None, len(self.forced_exc))
+
+        def set_state(self, gru_a=None, gru_b=None, cond_a=None, cond_b=None):
+            arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (gru_a, gru_b, cond_a, cond_b)]
+            self.lib.oracle_lpcnet_set_state(self.h, *[None if a is None else _p(a) for a in arrs])
+
+        def sample_step(self, last_exc, sig_ulaw, pred_ulaw):
+            """One sample-network step on the current state: all 255 node logits ([0] unused)."""
+            logits = np.zeros(256, np.float32)
+            self.lib.oracle_lpcnet_sample_step(self.h, int(last_exc), int(sig_ulaw), int(pred_ulaw), _p(logits))
+            return logits
+
         def synthesize(self, feat):
             feat = np.ascontiguousarray(feat, dtype=np.float32)
             out = np.ones(160, dtype=np.int16)
@@ -152,6 +185,26 @@ class Oracle:
 
     def decoder(self, model, trace_cap=0):
         return Oracle.Decoder(self.lib, model, trace_cap)
+
+    # ---- known-answer hooks -------------------------------------------------------------------
+    def kiss99(self, seed4=None, srand: bytes = None):
+        ctx = np.zeros(4, np.uint32)
+        if srand is not None:
+            self.lib.oracle_kiss99_srand(_p(ctx), srand, len(srand))
+        else:
+            self.lib.oracle_kiss99_seed(_p(ctx), *[int(v) for v in seed4])
+        return ctx
+
+    def kiss99_draw(self, ctx, n, keep=1):
+        out = np.zeros(keep, np.uint32)
+        self.lib.oracle_kiss99_draw(_p(ctx), n, _p(out), keep)
+        return out
+
+    def celt_lpc(self, ac, p=16):
+        ac = np.ascontiguousarray(ac, dtype=np.float32)
+        lpc = np.zeros(p, np.float32)
+        err = self.lib.oracle_celt_lpc(_p(lpc), _p(ac), p)
+        return lpc, float(err)
 
     def lpc_from_cepstrum(self, model, cep):
         cep = np.ascontiguousarray(cep, dtype=np.float32)
