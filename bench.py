@@ -107,7 +107,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B = args.batch
-    lpcnet.ensure_model()                       # seeded synthetic weights (no checkpoint can be fetched offline)
+    lpcnet.load_model(synthetic=True)           # seeded synthetic weights, explicitly (no checkpoint can be fetched offline)
     feats = torch.from_numpy(np.stack([synthetic_features(rank * B + b, FRAMES) for b in range(B)])).cuda()
     out = torch.empty((B, FRAMES * FRAME), dtype=torch.int16, device="cuda")
     wire = out.view(torch.uint8)                # RCCL has no int16 type: the PCM shard travels as bytes

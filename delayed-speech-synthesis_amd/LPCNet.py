@@ -23,10 +23,10 @@ class LPCNet:
     def __init__(self):
         L = _dss.load()
         try:
-            _host.ensure_model()
+            _host.ensure_model()        # $DSS_LPCNET_WEIGHTS or an explicit load_model(); never random weights by default
             self._st = L.lpcnet_create()
-        except _dss.DssError:
-            self._st = None
+        except _dss.DssError as e:
+            raise MemoryError(str(e)) from None                 # LPCNet.pyx:16-17: a failed create is a MemoryError
         if not self._st:
             raise MemoryError(L.dss_last_error().decode())      # LPCNet.pyx:16-17
         self._L = L
@@ -64,8 +64,12 @@ class LPCFeatureEncoder:
     LPCNET_FRAME_SIZE: int = 160
 
     def __init__(self):
-        raise NotImplementedError("LPCFeatureEncoder (corpus preparation) is outside the accelerated hot path; "
-                                  "see DESIGN.md 'Out of scope'")
+        # LPCNet.pyx:53-56: lpcnet_encoder_create() == NULL -> MemoryError.  libdss_hip.so exports the encoder symbols
+        # (cLPCNet.pxd:15-19) and its create returns NULL: corpus preparation is outside the accelerated path.
+        st = _dss.load().lpcnet_encoder_create()
+        if not st:
+            raise MemoryError(_dss.load().dss_last_error().decode())
+        raise MemoryError("unexpected encoder state from libdss_hip")
 
 
 class LPCFeatureFile:

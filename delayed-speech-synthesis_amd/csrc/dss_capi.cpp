@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -32,6 +33,8 @@ void dss_set_error(const char *fmt, ...)
 extern "C" const char *dss_last_error(void) { return g_err; }
 
 static thread_local int g_device = -1;
+// while upload_model() runs: the list every dev_upload() allocation is recorded in (so a model can be freed)
+static thread_local std::vector<std::pair<int, void *>> *g_track = nullptr;
 
 static int ensure_device()
 {
@@ -67,6 +70,12 @@ extern "C" int dss_set_device(int device)
     return DSS_OK;
 }
 
+extern "C" int dss_current_device(void)
+{
+    if (ensure_device()) return DSS_ENODEV;
+    return g_device;
+}
+
 extern "C" const char *dss_version(void)
 {
     static char buf[256];
@@ -84,6 +93,7 @@ static int dev_upload(const T *host, size_t count, T **out)
 {
     T *d = nullptr;
     DSS_HIP_CHECK(hipMalloc((void **)&d, count * sizeof(T) + 16));
+    if (g_track) { int dv = 0; hipGetDevice(&dv); g_track->emplace_back(dv, (void *)d); }
     DSS_HIP_CHECK(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
     *out = d;
     return DSS_OK;
@@ -106,13 +116,25 @@ struct HostModel {
     std::vector<char> blob;
     dss_blob_header h;
     double bytes_per_sample = 0;
+    int refs = 0;                      // decoder batches created from this model (guarded by g_model_mu)
     // per-device uploads
     std::vector<DssModelDev> dev;      // index = device id
     std::vector<char> dev_ready;
+    std::vector<std::pair<int, void *>> dev_allocs;   // (device, pointer) of everything upload_model() allocated
 };
 
 static std::mutex g_model_mu;
 static HostModel *g_model = nullptr;
+
+// free a model's device memory and the host copy (caller holds g_model_mu; refs must be 0)
+static void free_model(HostModel *hm)
+{
+    int cur = -1;
+    hipGetDevice(&cur);
+    for (auto &a : hm->dev_allocs) { hipSetDevice(a.first); hipFree(a.second); }
+    if (cur >= 0) hipSetDevice(cur);
+    delete hm;
+}
 
 static float host_ulaw2lin(float u)           // xiph common.h
 {
@@ -169,6 +191,10 @@ static int check_header(const dss_blob_header &h)
                       "(features 20, conv/dense 128, GRU A 384, GRU B 16, dual FC 256)");
         return DSS_EINVAL;
     }
+    if (h.gru_a_order != DSS_GRUA_INPUT_FIRST && h.gru_a_order != DSS_GRUA_RECUR_FIRST) {
+        dss_set_error("blob header: gru_a_order %d is neither 0 (input first) nor 1 (recurrent first)", h.gru_a_order);
+        return DSS_EINVAL;
+    }
     return DSS_OK;
 }
 
@@ -203,7 +229,10 @@ extern "C" int dss_lpcnet_load_model(const void *blob, size_t len)
     const double floats = 3.0 * (3 * na) + (double)hm->h.sparse_nblocks * 32 + 3 * na + 3.0 * nb * (na + nb) + 2.0 * nb * 8 + 16;
     hm->bytes_per_sample = 4.0 * floats + 2.0 + 80.0 / 160.0;
     std::lock_guard<std::mutex> lk(g_model_mu);
-    g_model = hm;     // earlier models stay alive: states created from them keep their device pointers
+    // an earlier model stays alive exactly as long as decoder batches created from it exist (they hold its device
+    // pointers); with none left it is freed here, otherwise when its last batch is destroyed
+    if (g_model && g_model->refs == 0) free_model(g_model);
+    g_model = hm;
     return DSS_OK;
 }
 
@@ -468,7 +497,9 @@ static int get_model(HostModel **out_hm, const DssModelDev **out)
     const int ndev = dss_device_count();
     if ((int)hm->dev.size() < ndev) { hm->dev.resize(ndev); hm->dev_ready.resize(ndev, 0); }
     if (!hm->dev_ready[g_device]) {
+        g_track = &hm->dev_allocs;
         rc = upload_model(hm, g_device, hm->dev[g_device]);
+        g_track = nullptr;
         if (rc) return rc;
         hm->dev_ready[g_device] = 1;
     }
@@ -482,6 +513,7 @@ static int get_model(HostModel **out_hm, const DssModelDev **out)
 // ------------------------------------------------------------------------------------------------------
 struct dss_lpcnet_batch {
     int device;
+    HostModel *host_model;        // keeps the model (and its device copy) alive
     const DssModelDev *model;
     DssBatchDev d;
     int last_utts = 0, last_frames = 0;
@@ -503,6 +535,8 @@ extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frame
     dss_lpcnet_batch *b = new dss_lpcnet_batch;
     memset(&b->d, 0, sizeof(b->d));
     b->device = g_device;
+    b->host_model = hm;
+    { std::lock_guard<std::mutex> lk(g_model_mu); hm->refs++; }
     b->model = m;
     DssBatchDev &d = b->d;
     d.max_utts = max_utts; d.max_frames = max_frames;
@@ -547,9 +581,14 @@ extern "C" void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b)
     DssBatchDev &d = b->d;
     void *ptrs[] = {d.gru_a_state, d.gru_b_state, d.last_sig, d.last_exc, d.deemph, d.rng, d.frame_count, d.conv1_mem,
                     d.conv2_mem, d.old_lpc, d.in_buf, d.c1_buf, d.c2_buf, d.d1_buf, d.cond_buf, d.lpc_buf, d.frame_out,
-                    d.fc0, d.trace_exc, d.trace_pcm, b->d_feat, b->d_pcm, b->d_slots, b->d_counts};
+                    d.fc0, d.trace_exc, d.trace_pcm, d.trace_logits, (void *)d.force_exc, b->d_feat, b->d_pcm, b->d_slots, b->d_counts};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 3; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
+    {
+        std::lock_guard<std::mutex> lk(g_model_mu);
+        HostModel *hm = b->host_model;
+        if (hm && --hm->refs == 0 && hm != g_model) free_model(hm);     // a superseded model dies with its last batch
+    }
     delete b;
 }
 
@@ -581,6 +620,53 @@ extern "C" int dss_lpcnet_batch_enable_trace(dss_lpcnet_batch *b, int on)
         if (rc) return DSS_ENOMEM;
     }
     b->trace = on;      // 1 = excitation/pcm trace, 2 = diagnostic phase stamps (development only)
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_batch_force_excitation(dss_lpcnet_batch *b, const unsigned char *exc, int n_utts, int n_frames)
+{
+    if (!b) return DSS_EINVAL;
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    if (!exc) {                                   // back to free running
+        if (b->d.force_exc) hipFree((void *)b->d.force_exc);
+        if (b->d.trace_logits) hipFree(b->d.trace_logits);
+        b->d.force_exc = nullptr; b->d.trace_logits = nullptr;
+        return DSS_OK;
+    }
+    if (n_utts <= 0 || n_utts > b->d.max_utts || n_frames <= 0 || n_frames > b->d.max_frames) {
+        dss_set_error("forced excitation shape out of range"); return DSS_EINVAL;
+    }
+    if (!b->trace) { dss_set_error("teacher forcing needs dss_lpcnet_batch_enable_trace(b, 1 or 17) first"); return DSS_EINVAL; }
+    const size_t n = (size_t)n_utts * n_frames * DSS_FRAME_SIZE;
+    if (b->d.force_exc) hipFree((void *)b->d.force_exc);
+    if (b->d.trace_logits) hipFree(b->d.trace_logits);
+    b->d.force_exc = nullptr; b->d.trace_logits = nullptr;
+    unsigned char *de = nullptr;
+    if (dev_upload<unsigned char>(exc, n, &de)) return DSS_ENOMEM;
+    b->d.force_exc = de;
+    if (dev_alloc<float>(n * 256, &b->d.trace_logits)) return DSS_ENOMEM;
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_model_info(int *fast_path, int *zr_slots_max, int *h_slots_max, int *h_lds_bytes, int *gru_a_order)
+{
+    HostModel *hm; const DssModelDev *m;
+    int rc = get_model(&hm, &m);
+    if (rc) return rc;
+    int hmax = 0;
+    // recomputed from the blob (the device struct keeps only what the kernels need)
+    {
+        BlobView v;
+        if (view_blob(hm->blob, hm->h, v)) return DSS_EINVAL;
+        const int G = hm->h.gru_a / 8;
+        long pos = 0;
+        for (int g = 0; g < 3 * G; ++g) { const int c = v.gru_a_idx[pos]; if (g >= 2 * G) hmax = std::max(hmax, c); pos += 1 + c; }
+    }
+    if (fast_path) *fast_path = m->fast_ok;
+    if (zr_slots_max) *zr_slots_max = m->nzr_max;
+    if (h_slots_max) *h_slots_max = hmax;
+    if (h_lds_bytes) *h_lds_bytes = m->hblk_floats * 4;
+    if (gru_a_order) *gru_a_order = hm->h.gru_a_order;
     return DSS_OK;
 }
 
@@ -727,6 +813,12 @@ extern "C" int dss_lpcnet_batch_tap(dss_lpcnet_batch *b, int utt, int which, flo
                                   DSS_COND_STRIDE * sizeof(float), width * sizeof(float), F, hipMemcpyDeviceToHost));
         return DSS_OK;
     }
+    if (which == 5 && b->d.trace_logits) {
+        const size_t n = (size_t)F * DSS_FRAME_SIZE * 256;
+        if (n_floats < n) { dss_set_error("tap buffer too small"); return DSS_EINVAL; }
+        DSS_HIP_CHECK(hipMemcpy(out, b->d.trace_logits + (size_t)utt * n, n * sizeof(float), hipMemcpyDeviceToHost));
+        return DSS_OK;
+    }
     if ((which == 3 || which == 4) && b->d.trace_exc) {
         const size_t n = (size_t)F * DSS_FRAME_SIZE;
         if (n_floats < n) { dss_set_error("tap buffer too small"); return DSS_EINVAL; }
@@ -765,21 +857,72 @@ extern "C" void lpcnet_destroy(LPCNetState *st)
     delete st;
 }
 
+// The xiph ABI gives this call no error channel (void; cLPCNet.pxd:13) and its caller is a live prosthesis loop
+// (local/units.py:534-535): never abort the process.  On failure the frame is ZERO-FILLED (silence), the reason is
+// kept in dss_last_error(), counted in dss_error_count(), and printed to stderr the first time and then every 1000th.
+static std::atomic<long> g_synth_failures{0};
+
+extern "C" long dss_error_count(void) { return g_synth_failures.load(); }
+
+static void synth_failed(short *output, int N)
+{
+    if (output && N > 0) memset(output, 0, sizeof(short) * (size_t)N);
+    const long k = g_synth_failures.fetch_add(1);
+    if (k == 0 || k % 1000 == 0) fprintf(stderr, "libdss_hip: lpcnet_synthesize failed (%ld so far), frame zero-filled: %s\n", k + 1, g_err);
+}
+
 extern "C" void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N)
 {
-    if (!st || !features || !output) return;
+    if (!st || !features || !output) { dss_set_error("lpcnet_synthesize: null argument"); synth_failed(output, N); return; }
     if (N != DSS_FRAME_SIZE) {           // the reference only ever asks for one 160-sample frame (LPCNet.pyx:39)
         dss_set_error("lpcnet_synthesize: N must be %d, got %d", DSS_FRAME_SIZE, N);
-        fprintf(stderr, "libdss_hip: %s\n", g_err);
-        abort();
+        synth_failed(output, N);
+        return;
     }
-    if (dss_lpcnet_batch_synthesize(st->b, features, 1, 1, DSS_NB_FEATURES, output)) {
-        fprintf(stderr, "libdss_hip: lpcnet_synthesize failed: %s\n", g_err);   // void in the xiph ABI: fail loudly
-        abort();
-    }
+    if (dss_lpcnet_batch_synthesize(st->b, features, 1, 1, DSS_NB_FEATURES, output)) synth_failed(output, N);
 }
 
 extern "C" int lpcnet_get_size(void) { return (int)sizeof(LPCNetState); }
+
+// ---- encoder half of the bound ABI (cLPCNet.pxd:15-19; LPCNet.pyx:43-87) -----------------------------------------
+// The feature ENCODER (pitch search, Bark cepstrum of a PCM frame) is corpus preparation (prepare_corpus.py:72-73),
+// outside the accelerated path.  The symbols exist so that the reference's own LPCNet.pyx links against this library
+// unchanged; lpcnet_encoder_create() returns NULL, which the reference's wrapper turns into MemoryError
+// (LPCNet.pyx:53-56), so a caller finds out at construction time, not from wrong features.
+struct LPCNetEncState;
+extern "C" LPCNetEncState *lpcnet_encoder_create(void)
+{
+    dss_set_error("LPCNet feature encoder is not provided by libdss_hip (corpus preparation is outside the accelerated path)");
+    return nullptr;
+}
+extern "C" int lpcnet_encoder_init(LPCNetEncState *) { return -1; }
+extern "C" void lpcnet_encoder_destroy(LPCNetEncState *) {}
+extern "C" int lpcnet_compute_features(LPCNetEncState *, const short *, float (*features)[36])
+{
+    if (features) memset(features, 0, sizeof(float) * 4 * 36);
+    dss_set_error("lpcnet_compute_features: encoder not provided by libdss_hip");
+    return -1;
+}
+extern "C" int lpcnet_compute_single_frame_features(LPCNetEncState *, const short *, float *features)
+{
+    if (features) memset(features, 0, sizeof(float) * 36);
+    dss_set_error("lpcnet_compute_single_frame_features: encoder not provided by libdss_hip");
+    return -1;
+}
+// cLPCNet.pxd:22-23 declares decode_packet inside a stray header block; nothing calls it
+
+extern "C" int dss_selftest_exp10(const float *x, const float *comp, float *out, long n)
+{
+    if (!x || !comp || !out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    float *dx = nullptr, *dc = nullptr, *dout = nullptr;
+    rc = dev_upload<float>(x, (size_t)n, &dx) | dev_upload<float>(comp, (size_t)n, &dc) | dev_alloc<float>((size_t)n, &dout);
+    if (!rc) rc = dss_launch_exp10_selftest(dx, dc, dout, n, 0);
+    if (!rc && hipMemcpy(out, dout, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = DSS_ENODEV;
+    hipFree(dx); hipFree(dc); hipFree(dout);
+    return rc;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // HGA

@@ -113,6 +113,11 @@ struct DssBatchDev {
     const int *count_of;  // [n] frames of row i (<= n_frames of the call; 0 leaves the slot untouched)
     // trace (optional)
     float *trace_exc, *trace_pcm;   // [B][F*160]
+    // teacher forcing (tests; honoured by the TRACE instantiations only): sample k of row u takes the excitation
+    // force_exc[u*F*160 + k] instead of the sampled one, and the pre-threshold logits of all 255 tree nodes go to
+    // trace_logits[(u*F*160 + k)*256 + node]
+    const unsigned char *force_exc;
+    float *trace_logits;
 };
 
 // kernels (defined in the .hip files)
@@ -122,6 +127,7 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
                               int trace, hipStream_t s);
 int dss_launch_sample_network_generic(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
                                       int trace, hipStream_t s);
+int dss_launch_exp10_selftest(const float *d_x, const float *d_comp, float *d_out, long n, hipStream_t s);
 int dss_launch_lpcnet_reset(const DssModelDev &m, DssBatchDev &b, int utt, hipStream_t s);
 
 // ---- speech-segment gate (speech_gate.hip) ---------------------------------------------------------------

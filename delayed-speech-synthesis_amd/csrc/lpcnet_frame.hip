@@ -198,6 +198,23 @@ frame_lpc_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, i
     }
 }
 
+// ---- self-test of the one transcendental this path evaluates on the device ------------------------------------------
+// lpc_from_cepstrum's `pow(10.f, Ex[i]) * compensation[i]` (freq.c) is a double pow rounded to float after the
+// multiplication; the LPC taps are bit-exact only if the device's pow and the host libm's agree after that rounding.
+// tests/test_gpu_lpcnet.py sweeps the reachable exponent range through this kernel (same expression as line 141).
+__global__ void exp10_selftest_kernel(const float *__restrict__ x, const float *__restrict__ comp, float *__restrict__ out, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)(pow(10.0, (double)x[i]) * (double)comp[i]);
+}
+
+int dss_launch_exp10_selftest(const float *d_x, const float *d_comp, float *d_out, long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(exp10_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_x, d_comp, d_out, n);
+    DSS_HIP_CHECK(hipGetLastError());
+    return DSS_OK;
+}
+
 // ---- final stage: delayed lpc into frame_out, persistent state update ------------------------------------
 __global__ void __launch_bounds__(128)
 frame_finish_kernel(DssBatchDev b, int n_frames)

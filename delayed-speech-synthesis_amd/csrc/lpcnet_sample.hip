@@ -25,6 +25,8 @@
 //               the scalar recurrences: mu-law / de-emphasis / PCM bookkeeping, kiss99 thresholds, its own tree walk.
 // Summation order inside every row is exactly the C source's (one product at a time, ascending input),
 // and the library is built with -ffp-contract=off, so results are bit-identical to the scalar C path.
+#include <mutex>
+
 #include "dss_common.h"
 #include "lpcnet_device.h"
 
@@ -348,6 +350,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
     }
     const float u2l_c = L.ulaw2lin[(HAS_FC ? 128 + tid : tid - 256) & 255];   // this lane's excitation candidate (waves 0, 1, 4, 5)
     const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
+    const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;     // wave-uniform (kernel argument)
     int cur = 0;
     float st = L.state_a[0][unit];
     unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
@@ -402,8 +405,9 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 const float gz = ((cz + es0) + ep0) + ee0;                          // compute_gru_a_input
                 const float gr = ((cr + es1) + ep1) + ee1;
                 const float gh = ((ch + es2) + ep2) + ee2;
-                az = az + gz;                       // (bias + diag*state) + input, then the blocks in idx order
-                ar = ar + gr;
+                // nnet.c 2021 (default): (bias + diag*state) + input, then the blocks in idx order;
+                // nnet.c 2019-20 (blob flag): the blocks first, the input last
+                if (!recur_first) { az = az + gz; ar = ar + gr; }
                 if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[1] += t - ta; ta = t; }
                 // the block products were formed right after the previous sample's state update (under GRU B);
                 // what is left on the critical path are the dependent sums, z and r chains interleaved
@@ -418,6 +422,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                         az += PR[s2 + u].w; ar += PR[ZRC + s2 + u].w;
                     }
                 }
+                if (recur_first) { az = gz + az; ar = gr + ar; }
                 if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
                 float z, r;
                 dss_sigmoid_approx2(L.tansig, az, ar, z, r);
@@ -474,7 +479,15 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 s1 = ff0 * t1;
                 s2 = ff1 * t2;
                 s1 += s2;
-                const bool bit = thr_lv < s1;
+                bool bit = thr_lv < s1;
+                if constexpr (TRACE) {               // teacher forcing (tests): record every logit, bend the walk
+                    const size_t o = ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + i;
+                    if (b.trace_logits) b.trace_logits[o * 256 + tid] = tid ? s1 : 0.f;
+                    if (b.force_exc) {
+                        const int v = b.force_exc[o];                                   // bits b7..b0, b7 decided at level 0
+                        if ((tid ^ (1 << level)) == (v >> (8 - level))) bit = (v >> (7 - level)) & 1;
+                    }
+                }
                 const unsigned long long mask = __ballot(bit);
                 if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
             }
@@ -753,9 +766,12 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
     // two register-slot capacities are compiled: 10 per gate (no spills) and 12 (a few spilled registers)
     const bool z10 = m.nzr_max <= 10;
+    static std::mutex attr_mu;                  // states on different devices may launch from different threads
     static unsigned long long attr_set = 0;     // per device: the attribute belongs to the device's code object
     int dev = 0;
     DSS_HIP_CHECK(hipGetDevice(&dev));
+    {
+    std::lock_guard<std::mutex> attr_lk(attr_mu);
     if (!(attr_set >> (dev & 63) & 1)) {      // one workgroup uses (almost) the whole 160 KB of the CU
 #define DSS_SET_ATTR(K) DSS_HIP_CHECK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES))
         DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, false>)); DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, false>));
@@ -764,6 +780,7 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
         DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 10, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 12, false>));
 #undef DSS_SET_ATTR
         attr_set |= 1ull << (dev & 63);
+    }
     }
     const bool ragged = b.slot_of || b.count_of;
     if (ragged && trace == 2) { dss_set_error("phase stamps are taken on uniform calls only"); return DSS_EINVAL; }

@@ -94,6 +94,7 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
         for (int j = 0; j < DSS_LPC_ORDER; ++j) { last_sig[j] = 0; lpc[j] = 0; }
     }
     const int fc0 = b.fc0[utt];
+    const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;      // association of the z/r pre-activations
     int cur = 0;
     unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0;
@@ -149,8 +150,9 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
                 const float gr = ((cr + es[NA]) + ep[NA]) + ee[NA];
                 const float gh = ((ch + es[2 * NA]) + ep[2 * NA]) + ee[2 * NA];
                 const float st = L.state_a[cur][tid];
-                float az = (rbz + dgz * st) + gz;                                   // compute_sparse_gru
-                float ar = (rbr + dgr * st) + gr;
+                float az = rbz + dgz * st;                                          // compute_sparse_gru
+                float ar = rbr + dgr * st;
+                if (!recur_first) { az = az + gz; ar = ar + gr; }                  // nnet.c 2021: input before the blocks
                 float ah = rbh + dgh * st;
                 const char *xbase = reinterpret_cast<const char *>(L.state_a[cur]);
 #define DSS_GATE(G, ACC)                                                                         \
@@ -167,6 +169,7 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
                 DSS_GATE(1, ar)
                 DSS_GATE(2, ah)
 #undef DSS_GATE
+                if (recur_first) { az = gz + az; ar = gr + ar; }                    // nnet.c 2019-20: zrh = input; zrh += recur
                 const float z = dss_sigmoid_approx(L.tansig, az);
                 const float r = dss_sigmoid_approx(L.tansig, ar);
                 float h = ah * r + gh;
@@ -218,6 +221,8 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
                 s2 = ff1 * dss_tanh_approx(L.tansig, s2);
                 s1 += s2;
                 const int level = 31 - __clz(tid | 1);                               // node = (1 << level) | prefix
+                if (TRACE && b.trace_logits)
+                    b.trace_logits[(((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + i) * 256 + tid] = tid ? s1 : 0.f;
                 const bool bit = L.thr[level] < s1;
                 const unsigned long long mask = __ballot(bit);
                 if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
@@ -234,7 +239,8 @@ lpcnet_sample_generic_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *
                     const unsigned wbits = L.bits[node >> 5];
                     val = (val << 1) | ((wbits >> (node & 31)) & 1);
                 }
-                const int exc = val;
+                int exc = val;
+                if (TRACE && b.force_exc) exc = b.force_exc[((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + i];
                 float pcm = pred + L.ulaw2lin[exc];
                 if (TRACE && lane == 0) {
                     const size_t o = ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + i;

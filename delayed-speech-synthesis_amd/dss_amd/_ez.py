@@ -1,4 +1,4 @@
-"""ezmsg import guard.  The reference's units are ``ez.Unit`` subclasses (local/units.py:13); ezmsg is not part
+"""ezmsg import guard.  The reference's units are ``ez.Unit`` subclasses (reference local/units.py:13); ezmsg is not part
 of this image, so when it is missing a minimal stand-in with the same surface (Settings/State dataclasses, stream
 markers, subscriber/publisher decorators, apply_settings) lets the unit classes be constructed and their async
 handlers be driven directly (tests do exactly that).  With ezmsg installed the real package is used."""

@@ -26,11 +26,21 @@ def _declare(L):
         "dss_version": (C.c_char_p, []),
         "dss_device_count": (i, []),
         "dss_set_device": (i, [i]),
+        "dss_current_device": (i, []),
         "lpcnet_create": (vp, []),
         "lpcnet_init": (i, [vp]),
         "lpcnet_destroy": (None, [vp]),
         "lpcnet_synthesize": (None, [vp, vp, vp, i]),
         "lpcnet_get_size": (i, []),
+        "dss_error_count": (C.c_long, []),
+        "lpcnet_encoder_create": (vp, []),
+        "lpcnet_encoder_init": (i, [vp]),
+        "lpcnet_encoder_destroy": (None, [vp]),
+        "lpcnet_compute_features": (i, [vp, vp, vp]),
+        "lpcnet_compute_single_frame_features": (i, [vp, vp, vp]),
+        "dss_lpcnet_model_info": (i, [vp, vp, vp, vp, vp]),
+        "dss_lpcnet_batch_force_excitation": (i, [vp, vp, i, i]),
+        "dss_selftest_exp10": (i, [vp, vp, vp, C.c_long]),
         "dss_lpcnet_load_model": (i, [C.c_char_p, sz]),
         "dss_lpcnet_load_model_file": (i, [C.c_char_p]),
         "dss_lpcnet_bytes_per_sample": (C.c_double, []),

@@ -20,6 +20,37 @@ def design_filters(fs: int = 1000, l_freq: float = 70, h_freq: float = 170, orde
     return hg, fh, sosfilt_zi(hg), sosfilt_zi(fh)
 
 
+_TABLES = None
+_checked = False
+
+
+def reference_filters(fs: int = 1000, l_freq: float = 70, h_freq: float = 170):
+    """The filters HighGammaExtractor uses.  For the reference's configuration (fs 1000, 70-170 Hz: units.py:102,
+    config/debug_settings.ini:19) the 2 x 8 x 6 coefficient tables and their unit-step states SHIPPED with the package
+    (dss_amd/data/, the tables the golden HGA frames were generated with) are returned, so the bit-match with the
+    reference chain does not depend on the scipy build on the box; design_filters() is compared with them once and a
+    difference is reported.  Any other configuration is designed with scipy."""
+    global _TABLES, _checked
+    if (int(fs), float(l_freq), float(h_freq)) != (1000, 70.0, 170.0):
+        return design_filters(fs, l_freq, h_freq)
+    if _TABLES is None:
+        import os
+        with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "hga_filters_fs1000_70_170.npz")) as g:
+            _TABLES = tuple(np.ascontiguousarray(g[k], dtype=np.float64) for k in ("sos_hg", "sos_fh", "zi_hg", "zi_fh"))
+    if not _checked:
+        _checked = True
+        try:
+            same = all(np.array_equal(a, b) for a, b in zip(design_filters(fs, l_freq, h_freq), _TABLES))
+        except Exception:           # scipy absent or failing: the tables are all that is needed
+            same = True
+        if not same:
+            import warnings
+            warnings.warn("scipy on this machine designs different Butterworth sections than the shipped tables "
+                          "(scipy version skew); using the shipped tables, which the golden HGA frames were made with",
+                          RuntimeWarning, stacklevel=2)
+    return tuple(a.copy() for a in _TABLES)
+
+
 def num_windows(T: int, sr: int, wl: float, ws: float) -> int:
     return int(_lib.load().dss_hga_num_windows(int(T), int(sr), wl, ws))
 
@@ -44,7 +75,7 @@ class HgaExtractorGPU:
                  window_shift: float = 0.01, filters=None):
         L = _lib.require_gpu()
         self._L = L
-        hg, fh, zi_hg, zi_fh = filters if filters is not None else design_filters(fs)
+        hg, fh, zi_hg, zi_fh = filters if filters is not None else reference_filters(fs)
         hg, fh = (np.ascontiguousarray(a, dtype=np.float64) for a in (hg, fh))
         zi_hg, zi_fh = (np.ascontiguousarray(a, dtype=np.float64) for a in (zi_hg, zi_fh))
         if hg.shape != fh.shape or hg.shape[1] != 6:
@@ -99,14 +130,8 @@ class HgaExtractorGPU:
     def set_frontend_from_transforms(self, c_raw: int, select_all, car, select_sub) -> None:
         """Build the fused front end from the reference's three pre-transform objects (decode_online.py:65-85):
         SelectElectrodesFromBothGrids -> CommonAverageReferencing -> SelectElectrodesOverSpeechAreas."""
-        sel1 = np.asarray(select_all.grid_mapping, dtype=np.int64)          # column of raw for each mid channel
-        sel2 = np.asarray(select_sub.speech_grid_mapping, dtype=np.int64)   # mid channel of each output channel
-        grid_of_mid = np.full(len(sel1), -1, dtype=np.int64)
-        comp_lists = []
-        for g, (used, applied) in enumerate(zip(car.selection_masks_computation, car.selection_masks_application)):
-            grid_of_mid[np.nonzero(applied)[0]] = g
-            comp_lists.append(sel1[np.nonzero(used)[0]])                    # ascending mid index = numpy's order
-        self.set_frontend(c_raw, sel1[sel2], grid_of_mid[sel2], comp_lists)
+        from .electrodes import frontend_from_transforms
+        self.set_frontend(c_raw, *frontend_from_transforms(select_all, car, select_sub))
 
     def extract_raw(self, raw: np.ndarray) -> np.ndarray:
         """(S, n, c_raw) raw amplifier packets -> (S, W, C) frames, front end + filters + log power on the GPU."""

@@ -21,27 +21,58 @@ NB_FEATURES = 20
 _model_loaded = False
 
 
-def load_model(blob: Optional[bytes] = None, path: Optional[str] = None) -> None:
-    """Make a weight blob the process-wide model (what lpcnet_create()/LPCNet() bind to)."""
+class NoModelError(_lib.DssError):
+    pass
+
+
+def load_model(blob: Optional[bytes] = None, path: Optional[str] = None, synthetic: bool = False) -> None:
+    """Make a weight blob the process-wide model (what lpcnet_create()/LPCNet() bind to).
+
+    Exactly one of ``blob`` / ``path`` / ``synthetic=True``.  The synthetic model (seeded random weights of the
+    published architecture) exists for tests and benchmarks only -- it produces noise, not speech -- so it is never
+    chosen implicitly."""
     global _model_loaded
     L = _lib.load()
+    if sum(x is not None for x in (blob, path)) + bool(synthetic) != 1:
+        raise ValueError("load_model needs exactly one of blob=, path= or synthetic=True")
     if path is not None:
         _lib.check(L.dss_lpcnet_load_model_file(path.encode()))
     else:
-        if blob is None:
+        if synthetic:
             blob = synthetic_blob(0)
         _lib.check(L.dss_lpcnet_load_model(blob, len(blob)))
     _model_loaded = True
 
 
 def ensure_model() -> None:
-    """Load $DSS_LPCNET_WEIGHTS if set, else the seeded synthetic model (real xiph weights cannot be
-    fetched offline)."""
+    """Bind the process-wide model: an explicitly loaded one, else the file named by $DSS_LPCNET_WEIGHTS, else -- ONLY
+    when $DSS_LPCNET_SYNTHETIC=1 (tests, bench.py) -- the seeded synthetic model.  Without any of them this raises:
+    a prosthesis must never play noise from random weights because a path was forgotten (the C ABI fails the same
+    way, DSS_ENOMODEL)."""
     import os
     if _model_loaded:
         return
     p = os.environ.get("DSS_LPCNET_WEIGHTS")
-    load_model(path=p) if p else load_model()
+    if p:
+        load_model(path=p)
+    elif os.environ.get("DSS_LPCNET_SYNTHETIC") == "1":
+        load_model(synthetic=True)
+    else:
+        raise NoModelError("no LPCNet weights: set DSS_LPCNET_WEIGHTS to a blob converted with `python -m "
+                           "dss_amd.nnet_data nnet_data.c model.blob`, or call dss_amd.lpcnet.load_model(); "
+                           "DSS_LPCNET_SYNTHETIC=1 selects random test weights (noise, not speech)")
+
+
+def model_info() -> dict:
+    """Which sample-rate kernel the loaded model runs on (``dss_lpcnet_model_info``)."""
+    import ctypes
+    L = _lib.require_gpu()
+    v = [ctypes.c_int(0) for _ in range(5)]
+    _lib.check(L.dss_lpcnet_model_info(*[ctypes.byref(x) for x in v]))
+    keys = ("fast_path", "zr_slots_max", "h_slots_max", "h_lds_bytes", "gru_a_order")
+    info = {k: int(x.value) for k, x in zip(keys, v)}
+    info["kernel"] = "lpcnet_sample_kernel" if info["fast_path"] else "lpcnet_sample_generic_kernel"
+    return info
 
 
 def bytes_per_sample() -> float:
@@ -51,14 +82,28 @@ def bytes_per_sample() -> float:
 class LPCNetBatch:
     """B persistent decoder states on one GPU."""
 
-    def __init__(self, max_utts: int, max_frames: int):
+    def __init__(self, max_utts: int, max_frames: int, device: Optional[int] = None):
         L = _lib.require_gpu()
+        if device is not None:
+            _lib.check(L.dss_set_device(int(device)))
         ensure_model()
         self._L = L
         self.max_utts, self.max_frames = int(max_utts), int(max_frames)
         self._h = L.dss_lpcnet_batch_create(self.max_utts, self.max_frames)
         if not self._h:
             raise _lib.DssError(L.dss_last_error().decode())
+        self.device = int(L.dss_current_device())
+        info = model_info()
+        if not info["fast_path"]:
+            import warnings
+            warnings.warn("LPCNet model exceeds the CU-resident kernel's capacities (z/r blocks per row group %d of 12, "
+                          "h blocks %d of 28, LDS image %d of 137728 B): running on the generic kernel, several times slower"
+                          % (info["zr_slots_max"], info["h_slots_max"], info["h_lds_bytes"]), RuntimeWarning, stacklevel=2)
+
+    def _check_device(self, t):
+        """Kernels of this batch run on self.device; a tensor from another GPU would be a silent peer access."""
+        if t.device.index != self.device:
+            raise ValueError(f"tensor on cuda:{t.device.index}, decoder batch on cuda:{self.device}")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -90,9 +135,12 @@ class LPCNetBatch:
         tensor (B, F*160).  Asynchronous on the current torch stream."""
         import torch
         assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        self._check_device(features)
         B, F, S = features.shape
         if out is None:
             out = torch.empty((B, F * FRAME_SIZE), dtype=torch.int16, device=features.device)
+        else:
+            self._check_device(out)
         s = torch.cuda.current_stream(features.device).cuda_stream if stream is None else stream
         _lib.check(self._L.dss_lpcnet_batch_synthesize_dev(self._h, features.data_ptr(), B, F, S, out.data_ptr(), s))
         return out
@@ -135,6 +183,7 @@ class LPCNetBatch:
         sequences.  Returns the int16 CUDA tensor (n, Fmax*160); row i is valid up to counts[i]*160."""
         import torch
         assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        self._check_device(features)
         n, F, S = features.shape
         c = np.ascontiguousarray(counts, dtype=np.int32)
         sl = None if slots is None else np.ascontiguousarray(slots, dtype=np.int32)
@@ -151,6 +200,15 @@ class LPCNetBatch:
     def enable_trace(self, on=True):
         _lib.check(self._L.dss_lpcnet_batch_enable_trace(self._h, int(on)))
 
+    def force_excitation(self, exc, n_frames: int):
+        """Teacher forcing (needs enable_trace): exc (n_utts, n_frames*160) uint8, or None to go back to sampling."""
+        if exc is None:
+            _lib.check(self._L.dss_lpcnet_batch_force_excitation(self._h, None, 0, 0))
+            return
+        e = np.ascontiguousarray(exc, dtype=np.uint8)
+        assert e.ndim == 2 and e.shape[1] == n_frames * FRAME_SIZE
+        _lib.check(self._L.dss_lpcnet_batch_force_excitation(self._h, e.ctypes.data, e.shape[0], int(n_frames)))
+
     def enable_timing(self, on=True):
         _lib.check(self._L.dss_lpcnet_batch_enable_timing(self._h, int(on)))
 
@@ -158,7 +216,7 @@ class LPCNetBatch:
         return float(self._L.dss_lpcnet_batch_kernel_ms(self._h, which))
 
     def tap(self, utt: int, which: int, n_frames: int) -> np.ndarray:
-        width = {0: 1152, 1: 48, 2: 16, 3: FRAME_SIZE, 4: FRAME_SIZE}[which]
+        width = {0: 1152, 1: 48, 2: 16, 3: FRAME_SIZE, 4: FRAME_SIZE, 5: FRAME_SIZE * 256}[which]
         out = np.empty((n_frames, width), dtype=np.float32)
         _lib.check(self._L.dss_lpcnet_batch_tap(self._h, utt, which, out.ctypes.data, out.size))
         return out

@@ -30,7 +30,7 @@ from .lpcnet import FRAME_SIZE, LPCNetBatch
 class _DecoderMixin:
     def _make_decoder(self, n_channels, decoder, seed):
         if decoder is None:
-            from local.models import BidirectionalSpeechSynthesisModel
+            from .models import BidirectionalSpeechSynthesisModel
             torch.manual_seed(seed)         # no trained checkpoint exists offline: seeded random weights
             decoder = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=n_channels)
         return decoder.eval().cuda()
@@ -109,7 +109,7 @@ class GatedStreamingPipeline(_DecoderMixin):
         self.hga = HgaExtractorGPU(n_streams, n_channels, fs=fs)
         self.decoder = self._make_decoder(n_channels, decoder, seed)
         if vad is None:
-            from local.models import UnidirectionalVoiceActivityDetector
+            from .models import UnidirectionalVoiceActivityDetector
             torch.manual_seed(seed + 1)     # no trained checkpoint exists offline: seeded random weights
             vad = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=n_channels)
         self.vad = vad.eval().cuda()

@@ -2,7 +2,8 @@
 (local/training.py:165-207): every ``.npy`` file of LPCNet features (N x 20) becomes a 16 kHz ``.wav`` of the
 same name.  The reference forks a pool and runs one utterance per process on a fresh ``LPCNet()``; here the
 pending files are synthesised together, one persistent workgroup per utterance, in batched GPU launches.
-(The rest of the reference's training.py -- dataset, checkpointing -- is training code and out of scope.)"""
+(The rest of the reference's training.py -- dataset, checkpointing -- is training code and out of scope;
+``python -m dss_amd.run train_bidirectional_model.py`` swaps this class into the user's own local.training.)"""
 from __future__ import annotations
 
 import logging
@@ -11,7 +12,7 @@ from typing import List
 
 import numpy as np
 
-logger = logging.getLogger("training.py")
+logger = logging.getLogger("dss_amd.synthesis_queue")
 
 
 class AsynchronousSynthesisQueue:
@@ -41,7 +42,7 @@ class AsynchronousSynthesisQueue:
 
     def _flush(self):
         from scipy.io.wavfile import write as wavwrite
-        from dss_amd.lpcnet import LPCNetBatch
+        from .lpcnet import LPCNetBatch
         jobs, self._pending = self._pending, []
         loaded = []
         for name in jobs:

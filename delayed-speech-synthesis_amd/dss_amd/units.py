@@ -1,0 +1,145 @@
+"""The units of the online graph whose work moves to the GPU, with the surface of the
+reference's local/units.py classes of the same names (settings, stream names, message fields, handler names).
+
+  HighGammaExtractor   (units.py:97-161)   IIR x2 + warm-start frame buffer + log power as fused kernels per packet;
+                                           decode_online.py's three pre-transforms collapse into the GPU front end
+  HighGammaActivity    (units.py:185-207)  unit wrapper, msg.fs = 1 / window_shift
+  DelayedLPCNetVocoder (units.py:517-538)  a whole decoded segment per launch of the persistent sample-rate kernel;
+                                           one decoder state for the unit's lifetime, as units.py:524
+
+Everything else of the reference's unit module (ZMQ source, loggers, VAD gate, BiLSTM unit, SoX sink) is I/O or stock
+PyTorch and stays the user's own code: ``python -m dss_amd.run decode_online.py ...`` swaps exactly the classes above
+into the user's ``local.units`` and runs the script unchanged (dss_amd/run.py).  Without ezmsg installed the
+classes are built on a small stand-in (dss_amd/_ez.py) so they can be constructed and driven directly.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import replace
+from typing import AsyncGenerator, Callable, List, Optional
+
+import numpy as np
+
+from ._ez import TimeSeriesMessage, ez
+
+logger = logging.getLogger("dss_amd.units")
+Transforms = Optional[List[Callable]]
+
+
+class ClosedLoopMessage(TimeSeriesMessage):
+    """Message type of the reference graph (units.py:29-35): data, fs, plus arrival time / first-frame index."""
+    received_at: Optional[float] = None
+    previous_frames: Optional[float] = None
+
+
+import dataclasses as _dc                                  # the stand-in message type is a plain dataclass
+if _dc.is_dataclass(TimeSeriesMessage) and "received_at" not in {f.name for f in _dc.fields(ClosedLoopMessage)}:
+    ClosedLoopMessage = _dc.dataclass(ClosedLoopMessage)
+
+
+def _chain(functions):
+    def run(x):
+        for f in functions:
+            x = f(x)
+        return x
+    return run
+
+
+class HighGammaExtractor:
+    """70-170 Hz band-pass + 118-122 Hz band-stop (order-8 Butterworth SOS), 50 ms / 10 ms log-power frames
+    (units.py:102-161).  Filter memories and the 40-sample frame overlap live on the GPU and carry across calls."""
+
+    def __init__(self, fs, nb_electrodes, window_length=0.05, window_shift=0.01, l_freq: int = 70, h_freq: int = 170,
+                 pre_transforms: Transforms = None, post_transforms: Transforms = None):
+        from .hga import HgaExtractorGPU, reference_filters
+        self.fs, self.nb_electrodes = fs, nb_electrodes
+        self.window_length, self.window_shift = window_length, window_shift
+        self.pre_transform = _chain(pre_transforms) if pre_transforms is not None else None
+        self.post_transform = _chain(post_transforms) if post_transforms is not None else None
+        if not ((60 < l_freq < 120) or (120 < h_freq < 180)):
+            logger.warning("band edges %s-%s Hz lie outside the high-gamma range the reference recommends", l_freq, h_freq)
+        self.hg_filter, self.fh_filter, zi_hg, zi_fh = reference_filters(fs, l_freq, h_freq)
+        self._gpu = HgaExtractorGPU(1, nb_electrodes, fs=fs, window_length=window_length, window_shift=window_shift,
+                                    filters=(self.hg_filter, self.fh_filter, zi_hg, zi_fh))
+        # decode_online.py:65-85's chain (reorder -> per-grid CAR -> select) is recognised by the attributes its three
+        # objects expose and fused into the GPU front end; any other chain runs on the host as given
+        self._fused_pre = None
+        p = pre_transforms
+        if p is not None and len(p) == 3 and hasattr(p[0], "grid_mapping") and hasattr(p[1], "selection_masks_computation") \
+                and hasattr(p[2], "speech_grid_mapping") and len(p[2].speech_grid_mapping) == nb_electrodes:
+            self._fused_pre = tuple(p)
+
+    def extract_features(self, data: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if self._fused_pre is not None:
+            if getattr(self._gpu, "c_raw", None) != data.shape[1]:
+                self._gpu.set_frontend_from_transforms(data.shape[1], *self._fused_pre)
+            out = self._gpu.extract_raw(data)[0]
+        else:
+            if self.pre_transform is not None:
+                data = np.ascontiguousarray(self.pre_transform(data), dtype=np.float64)
+            out = self._gpu.extract(data)[0]
+        return self.post_transform(out) if self.post_transform is not None else out
+
+
+class HighGammaActivitySettings(ez.Settings):
+    fs: int
+    nb_electrodes: int
+    window_length: float = 0.05
+    window_shift: float = 0.01
+    l_freq: int = 70
+    h_freq: int = 170
+    pre_transforms: Transforms = None
+    post_transforms: Transforms = None
+
+
+class HighGammaActivityState(ez.State):
+    hg_extractor: Optional[HighGammaExtractor] = None
+
+
+class HighGammaActivity(ez.Unit):
+    SETTINGS: HighGammaActivitySettings
+    STATE: HighGammaActivityState
+    INPUT = ez.InputStream(TimeSeriesMessage)
+    OUTPUT = ez.OutputStream(TimeSeriesMessage)
+
+    def initialize(self) -> None:
+        s = self.SETTINGS
+        self.STATE.hg_extractor = HighGammaExtractor(
+            fs=s.fs, nb_electrodes=s.nb_electrodes, window_length=s.window_length, window_shift=s.window_shift,
+            l_freq=s.l_freq, h_freq=s.h_freq, pre_transforms=s.pre_transforms, post_transforms=s.post_transforms)
+
+    @ez.publisher(OUTPUT)
+    @ez.subscriber(INPUT)
+    async def process(self, msg: TimeSeriesMessage) -> AsyncGenerator:
+        frames = self.STATE.hg_extractor.extract_features(msg.data)
+        yield self.OUTPUT, replace(msg, data=frames, fs=1 / self.SETTINGS.window_shift)
+
+
+class LPCNetState(ez.State):
+    lpcnet = None
+
+
+class DelayedLPCNetVocoder(ez.Unit):
+    """(L, 20) decoded LPCNet features -> int16[L*160] at 16 kHz (units.py:531-538)."""
+    STATE: LPCNetState
+    INPUT = ez.InputStream(TimeSeriesMessage)
+    OUTPUT = ez.OutputStream(TimeSeriesMessage)
+    MAX_SEGMENT_FRAMES = 2200            # FilterSpeechSegments' ring holds 2000 frames (decode_online.py:116)
+
+    def initialize(self) -> None:
+        from .lpcnet import LPCNetBatch
+        self.STATE.lpcnet = LPCNetBatch(1, self.MAX_SEGMENT_FRAMES)
+
+    def shutdown(self) -> None:
+        if self.STATE.lpcnet is not None:
+            self.STATE.lpcnet.close()
+            self.STATE.lpcnet = None
+
+    @ez.subscriber(INPUT)
+    @ez.publisher(OUTPUT)
+    async def synthesize(self, msg: TimeSeriesMessage) -> AsyncGenerator:
+        feats = np.ascontiguousarray(msg.data, dtype=np.float32)
+        step = self.MAX_SEGMENT_FRAMES
+        pcm = [self.STATE.lpcnet.synthesize(feats[None, a:a + step])[0] for a in range(0, len(feats), step)]
+        yield self.OUTPUT, replace(msg, data=np.concatenate(pcm) if pcm else np.zeros(0, np.int16), fs=16000)

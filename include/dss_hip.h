@@ -5,9 +5,11 @@
  * Plain C, plain pointers and sizes; no torch / C++ types.  Every entry point names the reference
  * interface it replaces (file:line relative to the reference repository).
  *
- * Part 1 is a drop-in for the four xiph/LPCNet decoder symbols the reference's Cython wrapper binds
- * (extensions/lpcnet/cLPCNet.pxd:10-13): the reference's own LPCNet.pyx can be compiled against this
- * header + library unchanged (INTEGRATION.md shows how).
+ * Part 1 exports every xiph/LPCNet symbol the reference's Cython wrapper binds (extensions/lpcnet/cLPCNet.pxd:10-19):
+ * the four decoder entry points are implemented, the five feature-ENCODER entry points (corpus preparation, outside
+ * the accelerated path) are present and fail cleanly (create returns NULL -> the wrapper's MemoryError,
+ * LPCNet.pyx:53-56).  The reference's own LPCNet.pyx therefore compiles and links against this library with the two
+ * shim headers under include/compat/ (tests/test_cpu_boundary.py does exactly that; INTEGRATION.md shows the recipe).
  * Part 2 is the batched form of the same operator (what AsynchronousSynthesisQueue's process pool,
  * local/training.py:165-207, and the north-star batch configs need).
  * Part 3 is the HGA operator (extensions/hga/hga_optimized.pyx and HighGammaExtractor,
@@ -43,6 +45,9 @@ const char *dss_version(void);
 int dss_device_count(void);
 /* Select the HIP device used by objects created afterwards on this thread (default 0 / LOCAL_RANK). */
 int dss_set_device(int device);
+/* The device objects created next on this thread will live on (>= 0), or DSS_ENODEV.  Every object keeps the device
+ * it was created on and runs its kernels there; device pointers handed to *_dev entry points must belong to it. */
+int dss_current_device(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Part 1 -- xiph LPCNet decoder symbols, as bound by extensions/lpcnet/cLPCNet.pxd:10-13
@@ -62,6 +67,20 @@ void lpcnet_destroy(LPCNetState *st);
 void lpcnet_synthesize(LPCNetState *st, const float *features, short *output, int N);
 /* xiph lpcnet.h: size of the opaque state (reported for completeness; states live on the device). */
 int lpcnet_get_size(void);
+/* lpcnet_synthesize has no error channel (void).  It never aborts the process: on failure (N != 160, HIP error,
+ * NULL argument) the frame is zero-filled, the reason is left in dss_last_error(), and this process-wide counter is
+ * incremented (first failure and every 1000th are also printed to stderr). */
+long dss_error_count(void);
+
+/* cLPCNet.pxd:15-19 -- feature encoder (used only by prepare_corpus.py:72-73).  NOT provided: create returns NULL
+ * (the reference's LPCFeatureEncoder.__cinit__ raises MemoryError, LPCNet.pyx:53-56), the others return -1 and
+ * zero their output. */
+typedef struct LPCNetEncState LPCNetEncState;
+LPCNetEncState *lpcnet_encoder_create(void);
+int lpcnet_encoder_init(LPCNetEncState *st);
+void lpcnet_encoder_destroy(LPCNetEncState *st);
+int lpcnet_compute_features(LPCNetEncState *st, const short *pcm, float features[4][36]);
+int lpcnet_compute_single_frame_features(LPCNetEncState *st, const short *pcm, float features[36]);
 
 /* Weights are data in this build (include/dss_lpcnet_blob.h); xiph compiles them in (nnet_data.c,
  * extensions/lpcnet/setup.py:34-36). */
@@ -69,6 +88,14 @@ int dss_lpcnet_load_model(const void *blob, size_t len);
 int dss_lpcnet_load_model_file(const char *path);
 /* SURVEY.md 8(d) algorithmic bytes per output sample for the loaded model (0 if none). */
 double dss_lpcnet_bytes_per_sample(void);
+/* Which sample-rate kernel the loaded model runs on, and why (any pointer may be NULL):
+ *   fast_path     1 = CU-resident kernel (all weights in VGPRs/LDS), 0 = generic kernel (GRU A blocks streamed from
+ *                 L2, several times slower) because the model exceeds a capacity below;
+ *   zr_slots_max  largest z- or r-gate block count of a row group (capacity 12; at most 16 groups above 8);
+ *   h_slots_max   largest h-gate block count of a row group (capacity 28);
+ *   h_lds_bytes   LDS image of the h-gate blocks (capacity 137 728 B);
+ *   gru_a_order   dss_blob_header.gru_a_order of the model. */
+int dss_lpcnet_model_info(int *fast_path, int *zr_slots_max, int *h_slots_max, int *h_lds_bytes, int *gru_a_order);
 
 /* ------------------------------------------------------------------------------------------------
  * Part 2 -- batched decoder: B independent utterances / streams, one persistent workgroup each.
@@ -112,7 +139,16 @@ int dss_lpcnet_batch_synthesize_ragged(dss_lpcnet_batch *b, const float *feature
  * which = 3: per-sample excitation index (uint8 stored as float) [n_frames*160]; 4: pre-de-emphasis pcm float.
  * (3 and 4 need dss_lpcnet_batch_enable_trace(b, 1) before the call.) */
 int dss_lpcnet_batch_tap(dss_lpcnet_batch *b, int utt, int which, float *out, size_t n_floats);
+/* on: 0 = off, 1 = trace on the kernel the model selects, 17 = trace on the generic kernel. */
 int dss_lpcnet_batch_enable_trace(dss_lpcnet_batch *b, int on);
+/* Teacher forcing (test instrument; needs trace enabled): in the following calls sample k of row u takes the excitation
+ * index exc[u*n_frames*160 + k] (host array) instead of the sampled one -- the RNG advances as usual -- and tap 5
+ * returns the pre-threshold logits of all 255 tree nodes per sample, [n_frames*160][256] ([.][0] unused).  The calls
+ * must have this n_frames.  exc == NULL switches back to free running. */
+int dss_lpcnet_batch_force_excitation(dss_lpcnet_batch *b, const unsigned char *exc, int n_utts, int n_frames);
+/* Self-test of the only transcendental evaluated on the device on this path: out[i] = (float)(pow(10.0, x[i]) *
+ * comp[i]), the expression of freq.c lpc_from_cepstrum (host buffers).  See DESIGN.md section 2. */
+int dss_selftest_exp10(const float *x, const float *comp, float *out, long n);
 /* Average device time (ms) of the sample-rate kernel over the calls since the last query, measured with
  * HIP events on the stream the kernel was launched on; resets the accumulator.  Needs
  * dss_lpcnet_batch_enable_timing(b, 1). */

@@ -11,6 +11,8 @@ for p in (PKG, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the seeded synthetic LPCNet model is an explicit opt-in (dss_amd.lpcnet.ensure_model); tests use it throughout
+os.environ.setdefault("DSS_LPCNET_SYNTHETIC", "1")
 
 
 def pytest_configure(config):

@@ -1,0 +1,168 @@
+"""CPU tests of the host-side code around the hot path: the PyTorch model classes against golden vectors produced by
+the reference's own local/models.py, the wire/disk formats, the electrode tables and the fused
+front-end description against the CPU chain in oracle/ecog_chain_oracle.py, the shipped filter tables, and the runner
+that swaps the GPU units into a user's unchanged reference script."""
+import hashlib
+import os
+import struct
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def test_models_match_reference_golden(golden):
+    from dss_amd.models import BidirectionalSpeechSynthesisModel, UnidirectionalVoiceActivityDetector
+    g = golden("models.npz")
+    torch.manual_seed(0)
+    m = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64).eval()
+    assert sum(p.numel() for p in m.parameters()) == int(g["bilstm_params"][0]) == 378420
+    sd = m.state_dict()
+    assert set(sd) >= {"lstm.weight_ih_l0", "lstm.weight_hh_l1_reverse", "regressor.weight", "regressor.bias"}
+    flat = np.concatenate([v.numpy().ravel() for _, v in sorted(sd.items())])
+    assert np.array_equal(_sha(flat), g["bilstm_sd_sha"])            # same init stream => same checkpoint layout
+    with torch.no_grad():
+        y, state = m(torch.from_numpy(g["bilstm_in"]), m.create_new_initial_state(batch_size=1))
+    assert y.shape == (1, 100, 20) and state[0].shape == (4, 1, 100)
+    np.testing.assert_allclose(y.numpy(), g["bilstm_out"], rtol=0, atol=1e-6)
+    torch.manual_seed(1)
+    v = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64).eval()
+    assert sum(p.numel() for p in v.parameters()) == int(g["vad_params"][0]) == 311102
+    x = torch.from_numpy(g["bilstm_in"])
+    with torch.no_grad():
+        s = v.create_new_initial_state(batch_size=1)
+        y1, s = v(x[:, :4], s)
+        y2, s = v(x[:, 4:8], s)
+        y_none, _ = v(x[:, :4])                                        # state=None -> zero state
+    np.testing.assert_allclose(np.concatenate([y1.numpy(), y2.numpy()], axis=1), g["vad_out"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(y_none.numpy(), y1.numpy(), rtol=0, atol=0)
+
+
+def test_wire_and_disk_formats(tmp_path):
+    from dss_amd import formats as F
+    assert F.PACKET_TOPIC == bytes([4, 1, 2]) and F.PACKET_HEADER.size == 7
+    samples = np.arange(129 * 40, dtype=np.float32).reshape(129, 40)               # channel-major on the wire
+    pkt = struct.pack("=BBB HH", 4, 1, 2, 129, 40) + samples.tobytes()             # development_amplifier.py:14-25
+    arr = F.parse_packet(pkt)
+    assert arr.shape == (40, 129) and arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"]
+    assert np.array_equal(arr, samples.T.astype(np.float64))
+    assert F.build_packet(arr) == pkt and pkt[:3] == F.PACKET_TOPIC
+    with pytest.raises(ValueError):
+        F.parse_packet(b"\x04\x01")
+    # stream logs: BinaryLogger appends message.data.tobytes() (units.py:264-270)
+    rng = np.random.default_rng(0)
+    hga = [rng.standard_normal((4, 64)) for _ in range(5)]
+    lpc = [rng.standard_normal((n, 20)).astype(np.float32) for n in (100, 37)]
+    with open(tmp_path / "log.hga.f64", "wb") as fh:
+        for a in hga:
+            F.append_stream_log(fh, a)
+    with open(tmp_path / "log.lpc.f32", "wb") as fh:
+        for a in lpc:
+            F.append_stream_log(fh, a)
+    assert np.array_equal(F.read_stream_log(tmp_path / "log.hga.f64", 64, np.float64), np.concatenate(hga))
+    assert np.array_equal(F.read_stream_log(tmp_path / "log.lpc.f32", 20, np.float32), np.concatenate(lpc))
+    with pytest.raises(ValueError):
+        F.read_stream_log(tmp_path / "log.lpc.f32", 64, np.float32)
+    assert sum(1 for _ in F.iter_packets(np.zeros((130, 129)), 40)) == 3
+    # VAD label file (units.py:311-319) and feature files (LPCNet.pyx:90-115)
+    (tmp_path / "log.vad.lab").write_text(F.format_vad_label(250, 100) + F.format_vad_label(1000, 7))
+    assert (tmp_path / "log.vad.lab").read_text().splitlines()[0] == "2.50\t3.50\t100 frames"
+    assert F.read_vad_labels(tmp_path / "log.vad.lab") == [(2.5, 3.5, 100), (10.0, 10.07, 7)]
+    feats36 = rng.standard_normal((9, 36)).astype(np.float32)
+    feats36.tofile(tmp_path / "utt.f32")
+    assert np.array_equal(F.read_feature_file(tmp_path / "utt.f32"), feats36[:, :20])
+    import LPCNet
+    assert np.array_equal(np.stack(list(LPCNet.LPCFeatureFile(str(tmp_path / "utt.f32")))), feats36[:, :20])
+    assert F.pcm_to_s16le(np.array([1, -2, 32767], dtype=np.int16)) == struct.pack("<3h", 1, -2, 32767)
+
+
+def test_electrode_tables_and_frontend_description():
+    from dss_amd import electrodes as E
+    from ecog_chain_oracle import ZScore, reference_chain
+    assert len(E.GRID_COLUMNS) == 128 and sorted(E.GRID_COLUMNS) == list(range(128))
+    keep = E.speech_channels_zero_based()
+    assert len(keep) == 64 and not set(keep + 1) & set(E.BAD_CHANNELS)
+    both, car, speech = reference_chain()
+    # the oracle chain against closed forms (its only pins: the reference has no test for these classes)
+    x = np.random.default_rng(0).standard_normal((7, 129))
+    y = both(x)
+    assert y.shape == (7, 128) and np.array_equal(y[:, 0], x[:, 125])
+    out = car(y)
+    ok = np.ones(64, dtype=bool)
+    ok[[18, 37, 47, 51]] = False                                   # channels 19, 38, 48, 52 stay out of the mean
+    np.testing.assert_allclose(out[:, :64], y[:, :64] - y[:, :64][:, ok].mean(axis=1, keepdims=True), atol=1e-12)
+    np.testing.assert_allclose(out[:, 64:], y[:, 64:] - y[:, 64:].mean(axis=1, keepdims=True), atol=1e-12)
+    z = ZScore(np.full((1, 64), 2.0), np.full((1, 64), 4.0))(speech(out))
+    assert z.shape == (7, 64) and np.allclose(z, (speech(out) - 2.0) / 4.0)
+    # the front-end description built from the tables alone equals the one derived from the chain objects ...
+    a = E.reference_frontend()
+    b = E.frontend_from_transforms(both, car, speech)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert all(np.array_equal(p, q) for p, q in zip(a[2], b[2])) and [len(c) for c in a[2]] == [60, 64]
+    # ... and describes the chain: out[:, c] = raw[:, src_col[c]] - sequential mean over comp_lists[grid_of[c]]
+    src, gof, comp = a
+    want = speech(car(both(x)))
+    got = np.empty_like(want)
+    for c in range(64):
+        acc = np.zeros(7)
+        for col in comp[gof[c]]:
+            acc = acc + x[:, col]
+        got[:, c] = x[:, src[c]] - acc / len(comp[gof[c]])
+    assert np.array_equal(got, want)                                # bit-identical, including the summation order
+
+
+def test_shipped_filter_tables_are_what_scipy_designs_here(golden):
+    from dss_amd import hga
+    g = golden("hga_filters.npz")
+    tab = hga.reference_filters(1000, 70, 170)
+    for a, k in zip(tab, ("sos_hg", "sos_fh", "zi_hg", "zi_fh")):
+        assert np.array_equal(a, g[k])                              # the tables the golden HGA frames were made with
+    for a, b in zip(hga.design_filters(1000, 70, 170), tab):        # scipy in this image still reproduces them
+        assert np.array_equal(a, b)
+    other = hga.reference_filters(2000, 70, 170)                    # any other configuration is designed on the spot
+    assert other[0].shape == (8, 6) and not np.array_equal(other[0], tab[0])
+
+
+def test_runner_swaps_the_gpu_units_into_an_unchanged_user_script(tmp_path):
+    """python -m dss_amd.run <script>: the user's own local.units keeps every class except the accelerated ones."""
+    (tmp_path / "local").mkdir()
+    (tmp_path / "local" / "__init__.py").write_text("")
+    (tmp_path / "local" / "units.py").write_text(textwrap.dedent("""
+        import LPCNet                       # resolves to the drop-in module
+        from hga_optimized import WarmStartFrameBuffer
+        class HighGammaExtractor: origin = 'user'
+        class DelayedLPCNetVocoder: origin = 'user'
+        class BinaryLogger: origin = 'user'
+        class HighGammaActivity:
+            def make(self):
+                return HighGammaExtractor   # looked up at call time, like units.py:199-201
+    """))
+    (tmp_path / "script.py").write_text(textwrap.dedent("""
+        import sys
+        from local.units import HighGammaActivity, DelayedLPCNetVocoder, BinaryLogger
+        import LPCNet
+        print('ARGS', sys.argv[1:])
+        print('EXT', HighGammaActivity().make().__module__)
+        print('VOC', DelayedLPCNetVocoder.__module__)
+        print('LOG', BinaryLogger.origin)
+        print('LPCNET', LPCNet.__file__)
+    """))
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "delayed-speech-synthesis_amd"))
+    out = subprocess.run([sys.executable, "-m", "dss_amd.run", str(tmp_path / "script.py"), "cfg.ini", "--run"],
+                         env=env, text=True, capture_output=True, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr
+    assert "ARGS ['cfg.ini', '--run']" in out.stdout
+    assert "EXT dss_amd.units" in out.stdout and "VOC dss_amd.units" in out.stdout and "LOG user" in out.stdout
+    assert os.path.join("delayed-speech-synthesis_amd", "LPCNet.py") in out.stdout
+    assert "local.units.HighGammaExtractor: replaced" in out.stderr
+    assert "local.training.AsynchronousSynthesisQueue: left alone" in out.stderr      # this user tree has no training.py

@@ -1,5 +1,9 @@
-"""GPU tests of the unit surface and of the device-resident pipelines (configs 3 and 5)."""
+"""GPU tests of the accelerated units (dss_amd.units) and of the device-resident pipelines (configs 3 and 5)."""
 import asyncio
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 
 import numpy as np
 import pytest
@@ -16,7 +20,7 @@ async def _drive(gen):
 
 
 def test_high_gamma_activity_unit_matches_reference_golden(golden):
-    import local.units as U
+    import dss_amd.units as U
     g = golden("hga_frames.npz")
     unit = U.HighGammaActivity(U.HighGammaActivitySettings(fs=1000, nb_electrodes=64))
     unit.initialize()
@@ -31,14 +35,10 @@ def test_high_gamma_activity_unit_matches_reference_golden(golden):
 
 def test_extractor_with_pre_and_post_transforms(golden):
     """decode_online.py:65-97 wiring: 128-ch select -> CAR -> 64-ch select, then z-score after the log power."""
-    import local.units as U
-    from local.common import (CommonAverageReferencing, SelectElectrodesFromBothGrids, SelectElectrodesOverSpeechAreas,
-                              ZScoreNormalization)
-    both, speech = SelectElectrodesFromBothGrids(), SelectElectrodesOverSpeechAreas()
-    speech_grid = np.flip(np.arange(64, dtype=np.int16).reshape((8, 8)) + 1, axis=0)
-    motor_grid = np.flip(np.arange(64, dtype=np.int16).reshape((8, 8)) + 65, axis=0)
-    car = CommonAverageReferencing([19, 38, 48, 52], [speech_grid, motor_grid], np.arange(128) + 1)
-    post = ZScoreNormalization(np.full((1, 64), 3.0), np.full((1, 64), 2.0))
+    import dss_amd.units as U
+    from ecog_chain_oracle import ZScore, reference_chain          # CPU restatement of local/common.py's classes
+    both, car, speech = reference_chain()
+    post = ZScore(np.full((1, 64), 3.0), np.full((1, 64), 2.0))
     ex = U.HighGammaExtractor(1000, 64, pre_transforms=[both, car, speech], post_transforms=[post])
     raw = synthetic_ecog(77, 200, 129)
     assert ex._fused_pre is not None                       # reorder + CAR + select run in the GPU front-end kernel
@@ -54,7 +54,7 @@ def test_extractor_with_pre_and_post_transforms(golden):
 
 
 def test_vocoder_unit_segments_and_state_carry(oracle):
-    import local.units as U
+    import dss_amd.units as U
     from dss_amd import lpcnet
     blob = synthetic_blob(0)
     lpcnet.load_model(blob)
@@ -69,18 +69,16 @@ def test_vocoder_unit_segments_and_state_carry(oracle):
     voc.shutdown()
 
 
-def test_decoder_unit_on_gpu_matches_reference_golden(golden):
-    import local.units as U
-    from local.models import BidirectionalSpeechSynthesisModel
+def test_decoder_model_on_gpu_matches_reference_golden(golden):
+    """The BiLSTM the reference's RecurrentNeuralDecodingModel unit wraps (units.py:499-508): whole segment, fresh zero
+    state, on PyTorch-ROCm; golden output from the reference's own local/models.py on CPU."""
+    from dss_amd.models import BidirectionalSpeechSynthesisModel
     g = golden("models.npz")
     torch.manual_seed(0)
-    unit = U.RecurrentNeuralDecodingModel(U.RecurrentNeuralDecodingModelSettings(
-        path_to_model_weights=None, model=BidirectionalSpeechSynthesisModel,
-        params=dict(nb_layer=2, nb_hidden_units=100, nb_electrodes=64)))
-    unit.initialize()
-    assert unit.STATE.device == "cuda"
-    (_, msg), = asyncio.run(_drive(unit.decode(U.ClosedLoopMessage(data=g["bilstm_in"][0], fs=100))))
-    np.testing.assert_allclose(msg.data, g["bilstm_out"][0], rtol=0, atol=2e-5)     # MIOpen LSTM vs CPU LSTM, fp32
+    m = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64).eval().cuda()
+    with torch.no_grad():
+        y, _ = m(torch.from_numpy(g["bilstm_in"]).cuda(), m.create_new_initial_state(batch_size=1, device="cuda"))
+    np.testing.assert_allclose(y.cpu().numpy(), g["bilstm_out"], rtol=0, atol=2e-5)     # MIOpen LSTM vs CPU LSTM, fp32
 
 
 def test_segment_pipeline_config3(oracle, golden):
@@ -125,7 +123,7 @@ def test_asynchronous_synthesis_queue_file_contract(tmp_path, oracle):
     """.npy (N x 20) -> .wav 16 kHz, ragged lengths in one batch, bad files skipped."""
     from scipy.io.wavfile import read as wavread
     from dss_amd import lpcnet
-    from local.training import AsynchronousSynthesisQueue
+    from dss_amd.synthesis_queue import AsynchronousSynthesisQueue
     blob = synthetic_blob(0)
     lpcnet.load_model(blob)
     m = oracle.lpcnet_model(blob)

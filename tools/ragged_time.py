@@ -18,7 +18,7 @@ from dss_amd import lpcnet
 from dss_amd.lpcnet_weights import synthetic_features
 from dss_amd.pipeline import GatedStreamingPipeline
 
-lpcnet.ensure_model()
+lpcnet.load_model(synthetic=True)
 rng = np.random.default_rng(0)
 n = 1024
 counts = rng.integers(50, 301, n)
