@@ -5,7 +5,8 @@ One "step" = one pass of the hot path over one batch of synthetic input: every r
 slots (a fresh LPCNet per utterance, as local/training.py:193 does), runs the frame-rate network and the
 persistent sample-rate kernel over BATCH x 1-second utterances (100 x 20 float32 feature frames each,
 already resident in HBM) and, for N > 1, the int16 PCM shards are collected on rank 0 with one RCCL gather
-(the path's only exchange step).  Workload at N=1 = BASELINE.json configs[1]: batch 256, 1-s utterances.
+(the path's only exchange step).  Workload at N=1 = BASELINE.json configs[1]: batch 256, 1-s utterances;
+at N>1 = configs[3]: 1024 utterances per GPU (8192 on 8 GPUs), gathered on rank 0 (tools/scale.sh runs 1/2/4/8).
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
@@ -26,6 +27,10 @@ for p in (PKG, os.path.join(ROOT, "tests")):
 
 METRIC = "LPCNet 16kHz samples/s/GPU (×real-time) + ECoG→audio p50 latency"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TF = 157.3    # MI355X_MICROARCH.md: peak FP32 (vector), counts an FMA as 2 flops
+# The path's parity contract forbids fused multiply-add (-ffp-contract=off: the reference's extension is a generic
+# x86-64 build, separate multiply and add), so a MAC costs two VALU issues and the reachable vector peak is half.
+FP32_NOFMA_PEAK_TF = FP32_VECTOR_PEAK_TF / 2
 FRAMES = 100                   # 1-s utterances
 FRAME = 160
 
@@ -46,7 +51,24 @@ def _cpu_job(args):
     return int(pcm.shape[0])
 
 
+def _hga_job(args):
+    seed, n = args
+    import numpy as np
+    import oracle_api
+    from dss_amd.hga import reference_filters
+    from dss_amd.synthetic import synthetic_ecog
+    orc = oracle_api.Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+    hg, fh, zi_hg, zi_fh = reference_filters(1000)
+    filt = {"sos_hg": hg, "sos_fh": fh, "zi_hg": zi_hg, "zi_fh": zi_fh}
+    xs = [synthetic_ecog(seed + k, 1040, 64) for k in range(n)]
+    t0 = time.time()
+    for x in xs:                                   # a fresh extractor per trial (prepare_corpus.py:147-176)
+        orc.extractor(filt, 64).extract(x)
+    return n * 1.04, time.time() - t0
+
+
 def cpu_baseline(utt_per_core=2):
+    """LPCNet and HGA on the GPU box's host cores: `cores`-process pool (the reference's pattern) and ONE core."""
     import multiprocessing as mp
     so = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(so):
@@ -63,10 +85,25 @@ def cpu_baseline(utt_per_core=2):
         t0 = time.time()
         samples = sum(pool.map(_cpu_job, [(s, FRAMES) for s in range(n_utts)], chunksize=1))
         dt = time.time() - t0
+        # HGA: 1.04-s x 64-channel trials (config 3's unit), 8 per job
+        hga_res = pool.map(_hga_job, [(1000 + 8 * j, 8) for j in range(cores)], chunksize=1)
+    _cpu_job((10_001, 3))
+    t0 = time.time()
+    one = sum(_cpu_job((s, FRAMES)) for s in range(4))              # four 1-s utterances on ONE core (this process)
+    dt1 = time.time() - t0
+    sec1, t1 = _hga_job((2000, 8))
+    hga_pool = sum(r[0] for r in hga_res) / max(r[1] for r in hga_res)
     return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{n_utts} x 1-s utterances (seeds 0..{n_utts - 1}), one utterance per pool job, "
                       f"{cores}-process pool, oracle/liboracle.so (scalar C, gcc -O2 generic)",
-            "x_realtime": samples / dt / 16000.0}
+            "x_realtime": samples / dt / 16000.0,
+            "one_core": {"value": one / dt1, "unit": "samples/s", "cores": 1, "x_realtime": one / dt1 / 16000.0,
+                         "sample": "4 x 1-s utterances (seeds 0..3) in one process"},
+            "hga": {"value": hga_pool, "unit": "stream-seconds/s (64 ch @ 1 kHz)", "cores": cores, "kind": "port",
+                    "sample": f"{8 * cores} trials of 1.04 s x 64 ch, fresh filter state per trial, {cores}-process pool, "
+                              "oracle/liboracle.so (DF2T cascade + frame buffer + log power; bit-equal to the reference's "
+                              "scipy sosfilt + Cython chain)",
+                    "one_core": {"value": sec1 / t1, "unit": "stream-seconds/s", "cores": 1, "sample": "8 trials, one process"}}}
 
 
 def main():
@@ -74,11 +111,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU (configs[1]: 256)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="utterances per GPU (default: 256 = configs[1] at --gpus 1, 1024 = configs[3] at --gpus > 1)")
+    ap.add_argument("--latency-ticks", type=int, default=1500, help="streaming-latency leg: 1500 ticks = 60 s of stream time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the streaming-latency leg (profiling runs)")
     args = ap.parse_args()
 
+    if args.batch is None:
+        args.batch = 256 if args.gpus == 1 else 1024
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # convenience: re-launch under torch.distributed.run as a child (nothing has touched the GPU yet)
@@ -112,7 +153,8 @@ def main():
     out = torch.empty((B, FRAMES * FRAME), dtype=torch.int16, device="cuda")
     wire = out.view(torch.uint8)                # RCCL has no int16 type: the PCM shard travels as bytes
     gathered = [torch.empty_like(wire) for _ in range(world)] if (world > 1 and rank == 0) else None
-    dec = lpcnet.LPCNetBatch(B, FRAMES)
+    dec = lpcnet.LPCNetBatch(B, FRAMES, device=local_rank)
+    info = lpcnet.model_info()
 
     def step():
         dec.reset_async()
@@ -153,47 +195,80 @@ def main():
         from dss_amd.pipeline import StreamingPipeline
         sp = StreamingPipeline(128)
         sp.measure_latency(10)
-        lat = sp.measure_latency(150)
+        lat = sp.measure_latency(args.latency_ticks)
         latency = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
+                   "ticks": int(args.latency_ticks), "stream_seconds": args.latency_ticks * 0.04,
                    "config": "128 concurrent 64-ch ECoG streams, one 40-sample packet per stream per tick (4 frames): host "
                              "packet in -> HGA -> BiLSTM (chunk-wise, VAD gating off) -> LPCNet -> 640 int16 samples per "
                              "stream back on the host; structural floor of the reference (0.55 s + whole-segment "
                              "synthesis) not included"}
 
-    # HBM traffic of the dominant kernel per launch: PMC counters cannot be read from inside this process, so the
-    # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/*_pmc_traffic.json),
-    # valid for the default workload only
-    traffic = None
+    # HBM traffic and issue counters of the dominant kernel per launch: PMC counters cannot be read from inside this
+    # process, so they come from the committed rocprofv3 --pmc passes of this same command (profiles/), and are quoted
+    # only for the workload they were taken on
+    traffic, counters = None, None
+    tag = {256: "r2_b256", 1024: "r2_b1024"}.get(B)
     try:
-        if B == 256:
-            with open(os.path.join(ROOT, "profiles", "r1i_pmc_traffic.json")) as f:
-                traffic = float(json.load(f)["hbm_bytes_per_launch_corrected"]) / 1e9      # GB per launch
+        with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
+            traffic = float(json.load(f)["hbm_bytes_per_launch_corrected"]) / 1e9          # GB per launch
     except Exception:
         traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_issue.json")) as f:
+            counters = json.load(f)
+    except Exception:
+        counters = None
 
     if rank == 0:
         samples_per_step = world * B * FRAMES * FRAME
         value = samples_per_step * args.steps / dt
         bps = lpcnet.bytes_per_sample()                          # ~273 kB per output sample
-        alg_bytes_per_launch = bps * B * FRAMES * FRAME
-        achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
+        synth = B * (FRAMES - 2) * FRAME                         # samples the sample-rate kernel really computes per launch
+        # SURVEY.md 8(d) "algorithmic flops": 2 per weight touched (sparse blocks, diagonal, GRU B, the 8 visited dual-FC
+        # nodes) + the embedding adds; every one of them is a separate fp32 multiply or add (no FMA by contract)
+        macs = (bps - 2.5) / 4.0 - 16 - 3 * 1152
+        flops_per_sample = 2.0 * macs + 2 * 16 + 3 * 1152
+        achieved_tf = flops_per_sample * synth / (k_ms * 1e-3) / 1e12
+        alg_bytes_per_launch = bps * synth
+        hbm_equiv = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "valu",                 # fp32 vector ALU without FMA; the kernel's real ceiling
+            "achieved": achieved_tf, "peak": FP32_NOFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / FP32_NOFMA_PEAK_TF,
+            "traffic": traffic, "traffic_unit": "GB of HBM per launch (PMC, profiles/)",
+            "kernel": info["kernel"], "kernel_ms": k_ms, "frame_kernels_ms": f_ms,
+            "algorithmic_flops_per_sample": flops_per_sample, "samples_per_launch": synth,
+            "frac_of_fma_peak": achieved_tf / FP32_VECTOR_PEAK_TF,
+            "note": "useful fp32 operations (SURVEY 8d algorithmic flops) per second of the sample-rate kernel, against the "
+                    "fp32 vector peak WITHOUT fused multiply-add (157.3/2 TFLOP/s): bit-exactness with the scalar C reference "
+                    "forbids FMA and MFMA.  Weights are resident in VGPRs/LDS, so HBM is not the bound (see "
+                    "roofline_hbm_equiv and traffic).",
+        }
+        if counters:
+            c = counters.get("derived", {})
+            roofline["valu_issue_utilisation"] = c.get("valu_issue_utilisation")
+            roofline["counters_from"] = f"profiles/{tag}_pmc_issue.json"
+        hbm = {"bound": "hbm", "achieved": hbm_equiv, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_equiv / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_sample": bps, "algorithmic_GB_per_launch": alg_bytes_per_launch / 1e9,
+               "hbm_traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / HBM_PEAK_GBS) if traffic else None,
+               "note": "SURVEY 8(d) convention: weights touched once per output sample at fp32.  NOT a physical HBM figure -- "
+                       "those bytes are served from VGPRs/LDS, which is why it exceeds the HBM peak; the HBM traffic the "
+                       "counters see is hbm_traffic_frac_of_peak of peak."}
         line = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"LPCNet-only, batch={B} synthetic 1-s utterances per GPU (100x20 f32 features -> "
-                                   f"16000 int16 samples each), fresh decoder state per utterance, features resident in HBM"
+            "config": {"workload": (f"configs[1]: LPCNet-only, batch={B}" if world == 1 else
+                                    f"configs[3]: LPCNet batch={world * B} sharded over {world} GPUs, {B}")
+                                   + " synthetic 1-s utterances per GPU (100x20 f32 features -> "
+                                   "16000 int16 samples each), fresh decoder state per utterance, features resident in HBM"
                                    + (", PCM shards gathered on rank 0 with one RCCL gather" if world > 1 else ""),
                        "batch_per_gpu": B, "frames": FRAMES, "weights": "synthetic seed 0 (xiph weights unobtainable offline)",
-                       "parallelism": f"utterance-sharded x{world}"},
+                       "parallelism": f"utterance-sharded x{world}",
+                       "world_size": (dist.get_world_size() if world > 1 else 1),
+                       "gathered_bytes_per_step": (int(world * wire.numel()) if world > 1 else 0)},
             "x_realtime": value / 16000.0, "samples_per_s_per_gpu": value / world,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch (PMC, profiles/)",
-                         "algorithmic_GB_per_launch": alg_bytes_per_launch / 1e9,
-                         "kernel": "lpcnet_sample_kernel", "kernel_ms": k_ms, "frame_kernels_ms": f_ms,
-                         "algorithmic_bytes_per_sample": bps,
-                         "note": "algorithmic bytes = weights touched once per output sample at fp32 (SURVEY 8d); they are "
-                                 "served from LDS/registers/L2, so frac > HBM share is expected; see profiles/ for PMC traffic"},
+            "roofline": roofline,
+            "roofline_hbm_equiv": hbm,
             "cpu_baseline": cpu,
             "latency": latency,
         }

@@ -54,13 +54,18 @@ def synthesize_sharded(features: np.ndarray, synth: Callable[[np.ndarray], torch
     return gather_pcm(local, features.shape[0], dst=dst)
 
 
-def lpcnet_synth_fn(max_utts: int, n_frames: int):
-    """The production `synth`: a per-rank LPCNetBatch on the rank's GPU."""
+def lpcnet_synth_fn(max_utts: int, n_frames: int, device: Optional[int] = None):
+    """The production `synth`: a per-rank LPCNetBatch on the rank's GPU (LOCAL_RANK unless `device` is given).
+    torch's current device, the library's device and every tensor handed to it are pinned to the same index."""
+    import os
     from .lpcnet import LPCNetBatch
-    dec = LPCNetBatch(max_utts, n_frames)
+    dev = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
+    torch.cuda.set_device(dev)
+    dec = LPCNetBatch(max_utts, n_frames, device=dev)
 
     def run(block: np.ndarray) -> torch.Tensor:
-        dec.reset_async()
-        d = torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)).cuda()
-        return dec.synthesize_torch(d)
+        with torch.cuda.device(dev):
+            dec.reset_async()
+            d = torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)).to(f"cuda:{dev}")
+            return dec.synthesize_torch(d)
     return run

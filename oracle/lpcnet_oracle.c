@@ -415,6 +415,12 @@ static float celt_lpc(float *lpc, const float *ac, int p)      /* celt_lpc.c _ce
 
 float oracle_celt_lpc(float *lpc, const float *ac, int p) { return celt_lpc(lpc, ac, p); }
 
+/* the host libm side of the device-pow self-test: freq.c `pow(10.f, Ex[i])*compensation[i]` stored to float */
+void oracle_exp10_comp(const float *x, const float *comp, float *out, long n)
+{
+    for (long i = 0; i < n; ++i) out[i] = pow(10.f, x[i]) * comp[i];
+}
+
 void oracle_lpc_from_cepstrum(const oracle_lpcnet_model *m, float *lpc, const float *cepstrum)
 {
     float tmp[NB_BANDS], Ex[NB_BANDS], Xr[FREQ_SIZE], ac[LPC_ORDER + 1];

@@ -266,3 +266,139 @@ def test_config4_per_gpu_share_1024_utterances(golden, model):
     assert np.array_equal(pcm[0], g["utt0_pcm"]) and np.array_equal(pcm[1], g["utt1_pcm"])
     assert np.array_equal(pcm[1022], g["utt0_pcm"]) and np.array_equal(pcm[1023], g["utt1_pcm"])
     assert (pcm[0::2] == pcm[0]).all() and (pcm[1::2] == pcm[1]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: teacher-forced twin of tests/test_oracle_lpcnet_pins.py, the GRU A association flag, the device pow
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("generic", [False, True])
+def test_teacher_forced_logits_match_the_oracle(oracle, model, generic):
+    """SURVEY 7 hard-part 2, teacher-forced mode: both sides are fed the SAME excitation sequence, so one flipped
+    comparison cannot hide everything after it; all 255 node logits of every sample are compared.  Stated tolerance:
+    0 (array_equal) -- the kernels keep the oracle's operation order; the oracle's own logits are pinned against the
+    layer definitions within 2e-3 on the CPU (test_sample_step_teacher_forced_against_layer_definitions)."""
+    from dss_amd.lpcnet import LPCNetBatch
+    B, F = 2, 6
+    n = F * 160
+    feats = np.stack([synthetic_features(300 + b, F) for b in range(B)])
+    rng = np.random.default_rng(17)
+    exc = np.clip(np.rint(128 + rng.normal(0, 30, (B, n))), 0, 255).astype(np.uint8)
+    gpu = LPCNetBatch(B, F)
+    gpu.enable_trace(17 if generic else 1)
+    gpu.force_excitation(exc, F)
+    pcm = gpu.synthesize(feats)
+    for b in range(B):
+        dec = oracle.decoder(model, trace_cap=n)
+        dec.force(exc[b, 320:])                    # the first two frames are silent: no sample step runs in them
+        want = np.concatenate([dec.synthesize(feats[b, t]) for t in range(F)])
+        got_exc = gpu.tap(b, 3, F).reshape(-1)[320:].astype(np.uint8)
+        assert np.array_equal(got_exc, exc[b, 320:]) and np.array_equal(dec.trace_exc[:n - 320], exc[b, 320:])
+        logits = gpu.tap(b, 5, F).reshape(n, 256)[320:]
+        assert np.array_equal(logits, dec.forced_logits), (b, np.abs(logits - dec.forced_logits).max())
+        assert np.array_equal(gpu.tap(b, 4, F).reshape(-1)[320:], dec.trace_pcm[:n - 320])
+        assert np.array_equal(pcm[b], want)
+    # back to free running on the same object: sampled excitations again, bit-exact
+    gpu.force_excitation(None, F)
+    gpu.reset()
+    pcm = gpu.synthesize(feats)
+    m2 = oracle.lpcnet_utterance(model, feats[0])
+    assert np.array_equal(pcm[0], m2)
+
+
+def test_gru_a_recurrent_first_order_flag(oracle):
+    """dss_blob_header.gru_a_order = 1 (xiph nnet.c 2019-20 association): both kernels follow the oracle bit for bit,
+    and the teacher-forced states differ from the default order's in the last bits only."""
+    from dss_amd import lpcnet
+    from dss_amd.lpcnet import LPCNetBatch
+    from dss_amd.lpcnet_weights import GRUA_RECUR_FIRST
+    feats = np.stack([synthetic_features(800 + b, 8) for b in range(3)])
+    blob = synthetic_blob(0, gru_a_order=GRUA_RECUR_FIRST)
+    try:
+        lpcnet.load_model(blob)
+        assert lpcnet.model_info()["gru_a_order"] == 1
+        want = _oracle_pcm(oracle, blob, feats)
+        for generic in (False, True):
+            gpu = LPCNetBatch(3, 8)
+            gpu.enable_trace(17 if generic else 1)
+            assert np.array_equal(gpu.synthesize(feats), want), generic
+        # teacher-forced: the two orders are different float programs (logits differ somewhere) of one real function
+        exc = np.full((1, 8 * 160), 131, np.uint8)
+        logits = {}
+        for order in (0, 1):
+            b2 = synthetic_blob(0, gru_a_order=order)
+            lpcnet.load_model(b2)
+            gpu = LPCNetBatch(1, 8)
+            gpu.enable_trace(1)
+            gpu.force_excitation(exc, 8)
+            gpu.synthesize(feats[:1])
+            logits[order] = gpu.tap(0, 5, 8).reshape(-1, 256)[320:]
+            dec = oracle.decoder(oracle.lpcnet_model(b2))
+            dec.force(exc[0, 320:])
+            for t in range(8):
+                dec.synthesize(feats[0, t])
+            assert np.array_equal(logits[order], dec.forced_logits), order
+        assert not np.array_equal(logits[0], logits[1]) and np.abs(logits[0] - logits[1]).max() < 1e-3
+    finally:
+        lpcnet.load_model(synthetic_blob(0))
+
+
+def test_skewed_sparsity_selects_a_kernel_loudly(oracle):
+    """magnitude pruning gives skewed per-row-group block counts.  Whatever kernel such a model lands on,
+    the choice is visible (model_info, a RuntimeWarning for the generic kernel) and the output is bit-exact."""
+    import warnings
+    from dss_amd import lpcnet
+    from dss_amd.lpcnet import LPCNetBatch
+    feats = np.stack([synthetic_features(820 + b, 5) for b in range(2)])
+    try:
+        seen = set()
+        for skew in (0.05, 0.3):          # per-group maxima 16 / 34 and 49 / 51 z-r / h blocks against capacities 12 / 28
+            blob = synthetic_blob(7, skew=skew)
+            lpcnet.load_model(blob)
+            info = lpcnet.model_info()
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                gpu = LPCNetBatch(2, 5)
+            assert bool(w) == (not info["fast_path"])
+            if w:
+                assert "generic kernel" in str(w[0].message)
+            assert np.array_equal(gpu.synthesize(feats), _oracle_pcm(oracle, blob, feats)), (skew, info)
+            seen.add(info["kernel"])
+        assert "lpcnet_sample_generic_kernel" in seen       # both exceed the CU-resident capacities
+    finally:
+        lpcnet.load_model(synthetic_blob(0))
+
+
+def test_device_pow_equals_host_libm_after_the_float_rounding(oracle):
+    """frame_lpc_kernel evaluates (float)(pow(10., e) * compensation) on the device, everything else transcendental on
+    this path is a host-built table.  Sweep the reachable exponent range densely: 1.2e7 float32 exponents in [-9, 9]
+    (|cepstrum| up to ~25 after the idct scale) against glibc's pow through the C oracle's libm."""
+    import ctypes
+    from dss_amd import _lib
+    L = _lib.require_gpu()
+    n = 12_000_000
+    rng = np.random.default_rng(123)
+    x = np.concatenate([np.linspace(-9, 9, n // 2, dtype=np.float64), rng.uniform(-9, 9, n - n // 2)]).astype(np.float32)
+    comp_vals = np.array([0.8, 1, 1, 1, 1, 1, 1, 1, 0.666667, 0.5, 0.5, 0.5, 0.333333, 0.25, 0.25, 0.2, 0.166667, 0.173913],
+                         dtype=np.float32)
+    comp = comp_vals[rng.integers(0, 18, n)]
+    got = np.empty(n, np.float32)
+    _lib.check(L.dss_selftest_exp10(x.ctypes.data, comp.ctypes.data, got.ctypes.data, n))
+    want = np.empty(n, np.float32)
+    oracle.lib.oracle_exp10_comp.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+    oracle.lib.oracle_exp10_comp(x.ctypes.data, comp.ctypes.data, want.ctypes.data, n)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad.size, x[bad[:5]], got[bad[:5]], want[bad[:5]])
+
+
+def test_void_synthesize_never_aborts(model):
+    """cLPCNet.pxd:13 has no error channel: a bad call zero-fills the frame and is counted; the state keeps working."""
+    import LPCNet
+    from dss_amd import _lib
+    L = _lib.load()
+    net = LPCNet.LPCNet()
+    f = synthetic_features(9, 4)
+    before = L.dss_error_count()
+    out = np.ones(80, dtype=np.int16)
+    L.lpcnet_synthesize(net._st, f[0].ctypes.data, out.ctypes.data, 80)            # N != 160
+    assert not out.any() and L.dss_error_count() == before + 1 and b"must be 160" in L.dss_last_error()
+    assert net.synthesize(f[0]).shape == (160,)                                     # the object is still usable

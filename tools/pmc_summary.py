@@ -26,6 +26,7 @@ def per_kernel(path, counter):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else "batch 256 x 1-s utterances"
     fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     name = next(k for k in fetch if DOMINANT in k)
     f_kb, w_kb = fetch[name]["mean_KB"], write[name]["mean_KB"]
@@ -33,7 +34,7 @@ def main():
         "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
                    "--warmup 1 --no-cpu-baseline --no-latency",
         "kernel": name,
-        "workload": "batch 256 x 1-s utterances",
+        "workload": workload,
         "FETCH_SIZE_KB_per_launch": f_kb,
         "WRITE_SIZE_KB_per_launch": w_kb,
         "hbm_bytes_per_launch_corrected": (2.0 * f_kb + w_kb) * 1024.0,
