@@ -1,0 +1,174 @@
+// csrc/lpcnet_sample_common.h -- register-level building blocks shared by the two CU-resident sample-rate kernels
+// (lpcnet_sample.hip: one utterance per workgroup, latency-optimised; lpcnet_sample_multi.hip: several utterances per
+// workgroup in a software pipeline, throughput-optimised).  Every macro keeps the summation order of xiph's
+// sparse_sgemv_accum8x4 / sgemv_accum (src/vec.h generic path): one product at a time, ascending input.
+#pragma once
+#include "dss_common.h"
+#include "lpcnet_device.h"
+
+#define NA DSS_GRU_A
+#define NB DSS_GRU_B
+#define NB3 (3 * DSS_GRU_B)
+#define ZRC Z                             // template parameter: z/r register slots per gate (10 or 12)
+#define ZRL DSS_ZRC                       // slot stride of the host layout (zr_w, zr_col)
+#define HC DSS_HC
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+
+// where DSS_H_CHAIN leaves the finished h-gate pre-activation of unit `uh` (the including kernel may redefine it)
+#ifndef DSS_H_STORE
+#define DSS_H_STORE(V) L.ah[uh] = (V)
+#endif
+
+// one 8x4 block applied to one row: four products accumulated one at a time (sparse_sgemv_accum8x4 order)
+// z/r chunk C = slots 2C, 2C+1 of the z list and of the r list (Q[0..1] z, Q[2..3] r)
+#define DSS_ZR_COL(S) ((PZ[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu)      /* S in layout numbering: z s, r ZRL + s */
+#define DSS_ZR_LOADX(Q, C)                                                                       \
+    {                                                                                            \
+        Q[0] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(2 * (C)) * 16);               \
+        Q[1] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(2 * (C) + 1) * 16);           \
+        Q[2] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(ZRC + 2 * (C)) * 16);         \
+        Q[3] = *reinterpret_cast<const f32x4 *>(xbase + DSS_ZR_COL(ZRC + 2 * (C) + 1) * 16);     \
+    }
+#define DSS_ZR_MUL(Q, C)                                                                         \
+    {                                                                                            \
+        Q[0].lo = WZ[2 * (C)].lo * Q[0].lo;             Q[0].hi = WZ[2 * (C)].hi * Q[0].hi;             \
+        Q[1].lo = WZ[2 * (C) + 1].lo * Q[1].lo;         Q[1].hi = WZ[2 * (C) + 1].hi * Q[1].hi;         \
+        Q[2].lo = WZ[ZRC + 2 * (C)].lo * Q[2].lo;       Q[2].hi = WZ[ZRC + 2 * (C)].hi * Q[2].hi;       \
+        Q[3].lo = WZ[ZRC + 2 * (C) + 1].lo * Q[3].lo;   Q[3].hi = WZ[ZRC + 2 * (C) + 1].hi * Q[3].hi;   \
+    }
+#define DSS_ZR_ADD(Q)                                                                            \
+    {                                                                                            \
+        az += Q[0].x; ar += Q[2].x; az += Q[0].y; ar += Q[2].y;                                  \
+        az += Q[0].z; ar += Q[2].z; az += Q[0].w; ar += Q[2].w;                                  \
+        az += Q[1].x; ar += Q[3].x; az += Q[1].y; ar += Q[3].y;                                  \
+        az += Q[1].z; ar += Q[3].z; az += Q[1].w; ar += Q[3].w;                                  \
+    }
+// z/r block products of one lane for the coming sample: state vectors from LDS, weights from registers
+#define DSS_ZR_PRODUCTS(XBUF)                                                                    \
+    {                                                                                            \
+        const char *xb = reinterpret_cast<const char *>(XBUF);                                   \
+        _Pragma("unroll") for (int s2 = 0; s2 < ZRC; s2 += 2) {                                  \
+            if (s2 >= nzr) break;                                                                \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                      \
+                const f32x4 xz = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(s2 + u) * 16); \
+                const f32x4 xr = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(ZRL + s2 + u) * 16); \
+                PR[s2 + u].lo = WZ[s2 + u].lo * xz.lo;             PR[s2 + u].hi = WZ[s2 + u].hi * xz.hi;             \
+                PR[ZRC + s2 + u].lo = WZ[ZRC + s2 + u].lo * xr.lo; PR[ZRC + s2 + u].hi = WZ[ZRC + s2 + u].hi * xr.hi; \
+            }                                                                                    \
+        }                                                                                        \
+    }
+// h-gate chain of one lane: rbh + dgh*st, then its row group's blocks in idx order.  Chunk C = slots 2C, 2C+1;
+// block records (LDS) and state vectors of the next chunk are fetched while the current chunk's sums run.
+#define DSS_H_COL(S) ((PH[(S) >> 2] >> (8 * ((S) & 3))) & 0xFFu)
+#define DSS_H_LOAD(Q, C)                                                                         \
+    {                                                                                            \
+        Q[0] = *reinterpret_cast<const f32x4 *>(hw + (2 * (C)) * 128);                           \
+        Q[1] = *reinterpret_cast<const f32x4 *>(hw + (2 * (C) + 1) * 128);                       \
+        Q[2] = *reinterpret_cast<const f32x4 *>(xbase + DSS_H_COL(2 * (C)) * 16);                \
+        Q[3] = *reinterpret_cast<const f32x4 *>(xbase + DSS_H_COL(2 * (C) + 1) * 16);            \
+    }
+#define DSS_H_MAC(Q)                                                                             \
+    {                                                                                            \
+        const f32x2 p0 = Q[0].lo * Q[2].lo, p1 = Q[0].hi * Q[2].hi;                              \
+        const f32x2 p2 = Q[1].lo * Q[3].lo, p3 = Q[1].hi * Q[3].hi;                              \
+        ah += p0.x; ah += p0.y; ah += p1.x; ah += p1.y;                                          \
+        ah += p2.x; ah += p2.y; ah += p3.x; ah += p3.y;                                          \
+    }
+#define DSS_H_CHAIN(XBUF)                                                                        \
+    {                                                                                            \
+        const char *xbase = reinterpret_cast<const char *>(XBUF);                                \
+        f32x4 HA[4], HB[4];                                                                      \
+        float ah = rbh + dgh * (XBUF)[uh];                                                       \
+        DSS_H_LOAD(HA, 0)                                                                        \
+        _Pragma("unroll") for (int c = 0; c < HC / 2; c += 2) {                                  \
+            if (2 * c >= nh) break;                                                              \
+            if (2 * (c + 1) < nh) DSS_H_LOAD(HB, c + 1)                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_H_MAC(HA)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (2 * (c + 1) >= nh) break;                                                        \
+            if (2 * (c + 2) < nh) DSS_H_LOAD(HA, c + 2)                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_H_MAC(HB)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+        DSS_H_STORE(ah);                                                                         \
+    }
+// N inputs (multiple of 16) of the GRU B chain of one row.  Weights come from this lane's registers, the new
+// GRU A state from LDS (same address in every lane -> broadcast), fetched one group of 16 inputs ahead so the
+// LDS latency hides behind the previous group's arithmetic.  Products two at a time on aligned register
+// pairs (v_pk_mul_f32), sums strictly one at a time in input order.
+#define DSS_GB_GROUP(AV, G)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+        const f32x2 p0 = WB[2 * (4 * (G) + u)] * (AV)[u].lo;                                     \
+        const f32x2 p1 = WB[2 * (4 * (G) + u) + 1] * (AV)[u].hi;                                 \
+        acc += p0.x;                                                                             \
+        acc += p0.y;                                                                             \
+        acc += p1.x;                                                                             \
+        acc += p1.y;                                                                             \
+    }
+#define DSS_GB_GROUP_OFF(AV, G, WOFF)                                                            \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+        const f32x2 p0 = WB[(WOFF) + 2 * (4 * (G) + u)] * (AV)[u].lo;                            \
+        const f32x2 p1 = WB[(WOFF) + 2 * (4 * (G) + u) + 1] * (AV)[u].hi;                        \
+        acc += p0.x;                                                                             \
+        acc += p0.y;                                                                             \
+        acc += p1.x;                                                                             \
+        acc += p1.y;                                                                             \
+    }
+#define DSS_GB_LOAD(AV, AN, G)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
+        (AV)[u] = *reinterpret_cast<const f32x4 *>((AN) + 16 * (G) + 4 * u);
+// One s_waitcnt per group of four reads instead of the compiler's one per read (gfx9 encoding, vmcnt/expcnt left at
+// their maxima): a wave issues about one instruction per 5 cycles whatever its kind, waits included.
+#define DSS_WAIT_LGKM(N) __builtin_amdgcn_s_waitcnt(0xC07F | ((N) << 8))
+#define DSS_GB_CHAIN(AN, N)                                                                      \
+    {                                                                                            \
+        f32x4 avA[4], avB[4];                                                                    \
+        DSS_GB_LOAD(avA, AN, 0)                                                                  \
+        DSS_GB_CHAIN_RUN(AN, N)                                                                  \
+    }
+// the same with the first group's reads already issued by the caller (avA, avB declared there)
+#define DSS_GB_CHAIN_RUN(AN, N)                                                                  \
+    {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < (N) / 16; g += 2) {                                \
+            if (g + 1 < (N) / 16) DSS_GB_LOAD(avB, AN, g + 1)                                    \
+            __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch ahead of the arithmetic */ \
+            if (g + 1 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                       \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_GB_GROUP(avA, g)                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 2 < (N) / 16) DSS_GB_LOAD(avA, AN, g + 2)                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 1 < (N) / 16) {                                                              \
+                if (g + 2 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                   \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                DSS_GB_GROUP(avB, g + 1)                                                         \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+
+// ... and with the weights taken from WB[WOFF + ...] (a chain that starts in the middle of the lane's weights)
+#define DSS_GB_CHAIN_RUN_OFF(AN, N, WOFF)                                                                  \
+    {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < (N) / 16; g += 2) {                                \
+            if (g + 1 < (N) / 16) DSS_GB_LOAD(avB, AN, g + 1)                                    \
+            __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch ahead of the arithmetic */ \
+            if (g + 1 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                       \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_GB_GROUP_OFF(avA, g, WOFF)                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 2 < (N) / 16) DSS_GB_LOAD(avA, AN, g + 2)                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 1 < (N) / 16) {                                                              \
+                if (g + 2 < (N) / 16) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);                   \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                DSS_GB_GROUP_OFF(avB, g + 1, WOFF)                                                         \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+

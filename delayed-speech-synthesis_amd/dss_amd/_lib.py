@@ -54,6 +54,7 @@ def _declare(L):
         "dss_lpcnet_batch_synthesize_ragged_dev": (i, [vp, vp, vp, vp, i, i, i, vp, vp]),
         "dss_lpcnet_batch_tap": (i, [vp, i, i, vp, sz]),
         "dss_lpcnet_batch_enable_trace": (i, [vp, i]),
+        "dss_lpcnet_batch_set_multi": (i, [vp, i]),
         "dss_lpcnet_batch_enable_timing": (i, [vp, i]),
         "dss_lpcnet_batch_kernel_ms": (C.c_double, [vp, i]),
         "dss_gate_create": (vp, [i, i, i, C.c_double, i, i, i]),

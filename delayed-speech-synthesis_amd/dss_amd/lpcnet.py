@@ -209,6 +209,10 @@ class LPCNetBatch:
         assert e.ndim == 2 and e.shape[1] == n_frames * FRAME_SIZE
         _lib.check(self._L.dss_lpcnet_batch_force_excitation(self._h, e.ctypes.data, e.shape[0], int(n_frames)))
 
+    def set_multi(self, utterances_per_workgroup: int = 0):
+        """0 = automatic, -1 = latency kernel only, 3 / 4 = force the throughput kernel (dss_lpcnet_batch_set_multi)."""
+        _lib.check(self._L.dss_lpcnet_batch_set_multi(self._h, int(utterances_per_workgroup)))
+
     def enable_timing(self, on=True):
         _lib.check(self._L.dss_lpcnet_batch_enable_timing(self._h, int(on)))
 

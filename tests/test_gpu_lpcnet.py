@@ -402,3 +402,62 @@ def test_void_synthesize_never_aborts(model):
     L.lpcnet_synthesize(net._st, f[0].ctypes.data, out.ctypes.data, 80)            # N != 160
     assert not out.any() and L.dss_error_count() == before + 1 and b"must be 160" in L.dss_last_error()
     assert net.synthesize(f[0]).shape == (160,)                                     # the object is still usable
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# throughput kernel: 3 or 4 utterances software-pipelined through one workgroup (csrc/lpcnet_sample_multi.hip)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("U", [3, 4])
+def test_multi_utterance_kernel_bit_exact(oracle, model, U):
+    """Forced on small batches, including workgroups that are only partly filled (7 and 10 are not multiples of 3 / 4),
+    a one-frame call, and state carried over several calls (the second call starts with frame_count > 0, so its first
+    frames are NOT silent and every utterance record is initialised from the saved decoder state)."""
+    from dss_amd.lpcnet import LPCNetBatch
+    for B, F in ((7, 6), (10, 3), (1, 4)):
+        feats = np.stack([synthetic_features(1200 + b, F) for b in range(B)])
+        gpu = LPCNetBatch(B, F)
+        gpu.set_multi(U)
+        pcm = gpu.synthesize(feats)
+        for b in range(B):
+            assert np.array_equal(pcm[b], oracle.lpcnet_utterance(model, feats[b])), (U, B, F, b)
+    # chunked: 1, 1, 1, 2, 5 frames through one batch object vs one oracle decoder per utterance
+    B, F = 5, 10
+    feats = np.stack([synthetic_features(1300 + b, F) for b in range(B)])
+    gpu = LPCNetBatch(B, 5)
+    gpu.set_multi(U)
+    decs = [oracle.decoder(model) for _ in range(B)]
+    t = 0
+    for n in (1, 1, 1, 2, 5):
+        got = gpu.synthesize(feats[:, t:t + n])
+        for b in range(B):
+            want = np.concatenate([decs[b].synthesize(feats[b, t + q]) for q in range(n)])
+            assert np.array_equal(got[b], want), (U, t, n, b)
+        t += n
+    # and the latency kernel continues a state the throughput kernel left (and vice versa)
+    gpu.set_multi(-1)
+    more = synthetic_features(1400, 2)
+    got = gpu.synthesize(np.stack([more] * B))
+    for b in range(B):
+        want = np.concatenate([decs[b].synthesize(more[q]) for q in range(2)])
+        assert np.array_equal(got[b], want), (U, "latency kernel after throughput kernel", b)
+    gpu.set_multi(U)
+    got = gpu.synthesize(np.stack([more] * B))
+    for b in range(B):
+        want = np.concatenate([decs[b].synthesize(more[q]) for q in range(2)])
+        assert np.array_equal(got[b], want), (U, "throughput kernel after latency kernel", b)
+
+
+def test_multi_utterance_kernel_other_models(oracle):
+    """Recurrent-first association order and a model at the 12-slot z/r capacity, through the throughput kernel."""
+    from dss_amd import lpcnet
+    from dss_amd.lpcnet import LPCNetBatch
+    from dss_amd.lpcnet_weights import make_synthetic_weights, pack_blob
+    feats = np.stack([synthetic_features(1500 + b, 5) for b in range(9)])
+    try:
+        for blob in (synthetic_blob(0, gru_a_order=1), pack_blob(make_synthetic_weights(1))):
+            lpcnet.load_model(blob)
+            gpu = LPCNetBatch(9, 5)
+            gpu.set_multi(3)
+            assert np.array_equal(gpu.synthesize(feats), _oracle_pcm(oracle, blob, feats))
+    finally:
+        lpcnet.load_model(synthetic_blob(0))
