@@ -608,6 +608,7 @@ static int choose_multi(const DssModelDev &m, int n_utts, int multi)
     if (multi >= 3) return multi <= umax ? multi : 0;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 0;                                                // automatic choice is off until the throughput form measures faster
     if (n_utts <= cus) return 0;                             // the latency kernel already has a CU per utterance
     const double cost1 = (double)((n_utts + cus - 1) / cus) * 6.4;
     int best = 0;

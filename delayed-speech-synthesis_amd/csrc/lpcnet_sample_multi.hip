@@ -17,6 +17,14 @@
 //                         of b's next speculation
 //   ONE workgroup barrier per slot.
 //
+// STATUS (round 2, measured on MI355X, tools/multi_time.py, 1024 x 1-s utterances): bit-exact, but 213 ms per batch against
+// 172 ms for four rounds of the latency kernel -- a slot takes ~8.2 k cycles where the design needs < 4.3 k to pay.
+// The counters (tools/prof_multi.sh) show why: VALU issue and LDS array are each busy only a third of the time; every
+// phase of a role-A wave (products, dual-FC, h chain, speculation, sums) is a dependent chain that waits on LDS / L2
+// round trips, and with all eight waves active those round trips are about twice as long as in the latency kernel, where
+// the same phases run while most other waves sit at a barrier.  dss_lpcnet_batch_set_multi() therefore keeps this form
+// opt-in; the automatic choice is the latency kernel.  DESIGN.md section 5 has the numbers and what would change them.
+//
 // An utterance therefore advances one sample every U slots (3 slots of work; with U = 4 one slot of slack), and the
 // workgroup finishes one utterance-sample per slot.  All arithmetic, and its order, is that of lpcnet_sample.hip (same
 // macros, same helper functions): summation order of xiph's sparse_sgemv_accum8x4 / sgemv_accum, -ffp-contract=off,
