@@ -156,17 +156,19 @@ def weights_from_nnet_data(text: str, dims: LPCNetDims = LPCNetDims(), names: Op
     return w
 
 
-def convert(path_in: str, path_out: str, names: Optional[Dict[str, str]] = None) -> int:
+def convert(path_in: str, path_out: str, names: Optional[Dict[str, str]] = None, gru_a_order: int = 0) -> int:
+    """gru_a_order: which association order of compute_sparse_gru's z/r pre-activation the xiph revision the weights
+    came with uses (include/dss_lpcnet_blob.h): 0 = input before the blocks (nnet.c 2021), 1 = blocks first (2019-20)."""
     with open(path_in, "r", errors="replace") as f:
         w = weights_from_nnet_data(f.read(), names=names)
-    blob = pack_blob(w)
+    blob = pack_blob(w, gru_a_order=gru_a_order)
     with open(path_out, "wb") as f:
         f.write(blob)
     return len(blob)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) != 3:
-        sys.exit("usage: python -m dss_amd.nnet_data <nnet_data.c> <out.blob>")
-    n = convert(sys.argv[1], sys.argv[2])
+    if len(sys.argv) not in (3, 4):
+        sys.exit("usage: python -m dss_amd.nnet_data <nnet_data.c> <out.blob> [gru_a_order: 0 (default, xiph 2021) | 1 (2019-20)]")
+    n = convert(sys.argv[1], sys.argv[2], gru_a_order=int(sys.argv[3]) if len(sys.argv) == 4 else 0)
     print(f"wrote {sys.argv[2]}: {n} bytes")
