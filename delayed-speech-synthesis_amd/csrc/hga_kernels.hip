@@ -5,12 +5,17 @@
 //   WarmStartFrameBuffer.insert                     extensions/hga/hga_optimized.pyx:96-131
 //   compute_log_power_features                      extensions/hga/hga_optimized.pyx:27-47
 //
-// Three launches per call: (1) the IIR cascades with their sections spread over the 16 lanes of a DPP row (a column
-// advances one sample per step instead of one per 16 dependent biquads), (2) the windowed mean power with one lane per
-// (stream, window, channel) -- a 50-term sequential sum each, consecutive lanes = consecutive channels, so every access
-// is a coalesced row segment of the reference's (T, C) row-major layout -- and (3) the warm-start overlap copy.
+// ONE launch per call (hga_fused_kernel): the IIR cascades with their sections spread over the 16 lanes of a DPP row (a
+// column advances one sample per step instead of one per 16 dependent biquads); the filtered samples of a tile go into an
+// LDS ring instead of HBM, every window that has become complete is summed from the ring (a 50-term sequential sum per
+// (window, channel) lane, exactly array_sum_and_power's order), and the last `overlap` rows are left in the row buffer
+// for the next call.  Only the input, the W x C frames and 40 rows per column touch HBM: at 1024 streams x 1.04 s that
+// removes the 545 MB write + read of the filtered rows which the three-launch form (hga_filter_kernel +
+// hga_window_kernel + hga_overlap_kernel, kept as the fallback for window shapes whose ring would not fit LDS) needed.
 // Built with -ffp-contract=off: every product and sum rounds separately, as in scipy's C loop and in
 // the reference's Cython kernel, which is what makes the mean power bit-identical.
+#include <stdlib.h>
+
 #include "dss_common.h"
 
 struct HgaSos { double k[2][8][6]; };
@@ -158,6 +163,152 @@ hga_filter_kernel(const double *__restrict__ data, double *__restrict__ zi, doub
     }
 }
 
+// ---- fused form: filter tile -> LDS ring -> completed windows -> overlap rows -------------------------------------------
+// Same block shape and the same per-step code as hga_filter_kernel (16 columns x 16 section lanes).  `ring` holds the last
+// RING rows of the block's 16 columns in row coordinates (overlap / zero rows first, then the new samples at row0 + t);
+// RING >= frame_length + window shift + HGA_TT so that no row a pending window still needs is overwritten by the next tile.
+__global__ void __launch_bounds__(256)
+hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, double *__restrict__ rowbuf, double *__restrict__ out,
+                 HgaSos sos, int S, int C, int n, int nsec, int row0, int cap_rows, int zero_rows, int rows, int W, int overlap,
+                 int sr, float wl, float ws, int apply_log, int ring_mask)
+{
+    __shared__ double xs[HGA_TT + 1][16];
+    __shared__ double ys[HGA_TT][16];
+    __shared__ double coef[16][5];
+    __shared__ double dump[256];
+    extern __shared__ __attribute__((aligned(16))) double ring[];         // [ring_mask + 1][16]
+    const int tid = threadIdx.x, r = tid & 15, pib = tid >> 4;
+    const long total = (long)S * C;
+    const long pair0 = (long)blockIdx.x * 16;
+    long pair = pair0 + pib;
+    const bool valid = pair < total;
+    if (!valid) pair = total - 1;
+    const int s = (int)(pair / C), c = (int)(pair - (long)s * C);
+    const int nsec2 = 2 * nsec;
+    const bool has_sec = r < nsec2;
+    const bool is_last = r == nsec2 - 1;
+    char *const ybase = is_last ? reinterpret_cast<char *>(&ys[0][pib]) : reinterpret_cast<char *>(&dump[tid]);
+    const int ystride = is_last ? 16 * (int)sizeof(double) : 0;
+    const int f = has_sec ? r / nsec : 0, q = has_sec ? r - f * nsec : 0;
+    if (tid < 16) {
+        const int ff = tid < nsec2 ? tid / nsec : 0, qq = tid < nsec2 ? tid - ff * nsec : 0;
+        coef[tid][0] = sos.k[ff][qq][0]; coef[tid][1] = sos.k[ff][qq][1]; coef[tid][2] = sos.k[ff][qq][2];
+        coef[tid][3] = sos.k[ff][qq][4]; coef[tid][4] = sos.k[ff][qq][5];
+    }
+    double *zp = zi + (size_t)s * 2 * 8 * 2 * C + c;
+    double z0 = zp[((f * 8 + q) * 2 + 0) * (size_t)C], z1 = zp[((f * 8 + q) * 2 + 1) * (size_t)C];
+    // rows [0, row0) of the ring: zeros (CASE 2, pyx:116) or the overlap the previous call left (CASE 3, pyx:123-131)
+    for (int idx = tid; idx < row0 * 16; idx += 256) {
+        const int rr = idx >> 4, p = idx & 15;
+        const long pp = pair0 + p;
+        double v = 0.0;
+        if (rr >= zero_rows && pp < total) {
+            const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
+            v = rowbuf[((size_t)sp * cap_rows + rr) * C + cp];
+        }
+        ring[(rr & ring_mask) * 16 + p] = v;
+    }
+    __syncthreads();
+    const double b0 = coef[r][0], b1 = coef[r][1], b2 = coef[r][2], a1 = coef[r][3], a2 = coef[r][4];
+    const int steps = n + nsec2 - 1;
+    double y = 0.0;
+    int w_next = 0;                                        // first window not yet written (block-uniform)
+    for (int base = 0; base < steps; base += HGA_TT) {
+        __syncthreads();                                   // previous tile fully consumed
+        for (int idx = tid; idx < HGA_TT * 16; idx += 256) {
+            const int tt = idx >> 4, p = idx & 15;
+            const long pp = pair0 + p;
+            const int t = base + tt;
+            double v = 0.0;
+            if (t < n && pp < total) {
+                const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
+                v = data[((size_t)sp * n + t) * C + cp];
+            }
+            xs[tt][p] = v;
+        }
+        __syncthreads();
+        const int kend = min(base + HGA_TT, steps);
+        int k = base;
+        for (; k < kend && (k < nsec2 - 1 || k >= n); ++k) {
+            const double in = hga_shift_in(xs[k - base][pib], y);
+            const int t = k - r;
+            if (has_sec && t >= 0 && t < n) {
+                HGA_BIQUAD(in)
+                if (is_last) ys[k - base][pib] = y;
+            }
+        }
+        const int ksteady = min(kend, n);
+        {
+            char *yp = ybase + (k - base) * ystride;
+            const double *xp = &xs[k - base][pib];
+            double xcur = *xp;
+            for (; k < ksteady; ++k) {
+                xp += 16;
+                const double xnext = *xp;
+                const double in = hga_shift_in(xcur, y);
+                HGA_BIQUAD(in)
+                *reinterpret_cast<double *>(yp) = y;
+                yp += ystride;
+                xcur = xnext;
+            }
+        }
+        for (; k < kend; ++k) {
+            const double in = hga_shift_in(xs[k - base][pib], y);
+            const int t = k - r;
+            if (has_sec && t >= 0 && t < n) {
+                HGA_BIQUAD(in)
+                if (is_last) ys[k - base][pib] = y;
+            }
+        }
+        __syncthreads();
+        // the tile's finished samples join the ring at their row
+        for (int idx = tid; idx < HGA_TT * 16; idx += 256) {
+            const int tt = idx >> 4, p = idx & 15;
+            const int t = base + tt - (nsec2 - 1);
+            if (base + tt < kend && t >= 0 && t < n) ring[((row0 + t) & ring_mask) * 16 + p] = ys[tt][p];
+        }
+        __syncthreads();
+        // every window that is complete now: lane = (window, column), a sequential sum over its rows (pyx:9-22, 42-46)
+        int t_done = kend - (nsec2 - 1);
+        t_done = t_done < 0 ? 0 : (t_done > n ? n : t_done);
+        const int rows_done = row0 + t_done;
+        {
+            const int p = tid & 15, wi = tid >> 4;
+            const long pp = pair0 + p;
+            for (int w = w_next + wi; w < W; w += 16) {
+                const int start = hga_win_start(w, ws, sr);
+                const int stop = hga_win_stop(start, wl, sr);
+                if (stop > rows_done) break;
+                double sum = 0.0;
+                for (int rr = start; rr < stop; ++rr) {
+                    const double v = ring[(rr & ring_mask) * 16 + p];
+                    sum += v * v;
+                }
+                if (pp < total) {
+                    const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
+                    const double pw = sum / (double)(stop - start) + 0.01;
+                    out[((size_t)sp * W + w) * C + cp] = apply_log ? log(pw) : pw;
+                }
+            }
+            while (w_next < W && hga_win_stop(hga_win_start(w_next, ws, sr), wl, sr) <= rows_done) ++w_next;
+        }
+    }
+    __syncthreads();
+    // the last `overlap` rows become rows 0..overlap-1 of the next call (WarmStartFrameBuffer.remainder_data)
+    for (int idx = tid; idx < overlap * 16; idx += 256) {
+        const int kk = idx >> 4, p = idx & 15;
+        const long pp = pair0 + p;
+        if (pp < total) {
+            const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
+            rowbuf[((size_t)sp * cap_rows + kk) * C + cp] = ring[((rows - overlap + kk) & ring_mask) * 16 + p];
+        }
+    }
+    if (valid && has_sec) {
+        zp[((f * 8 + q) * 2 + 0) * (size_t)C] = z0;
+        zp[((f * 8 + q) * 2 + 1) * (size_t)C] = z1;
+    }
+}
+
 // ---- stage 2: windowed mean power ---------------------------------------------------------------------------------
 // A 256-thread block takes 8 consecutive windows x 32 consecutive channels of one stream: the rows those windows cover
 // (50 + 7*10 for the reference's 50 ms / 10 ms at 1 kHz) are staged once through LDS in 256-byte row segments instead
@@ -229,6 +380,20 @@ int dss_launch_hga(const DssHgaDev &h, const double *d_data, int n, int row0, in
     HgaSos sos;
     memcpy(&sos, h.sos, sizeof(sos));
     const long pairs = (long)h.S * h.C;
+    {   // fused form when the ring (frame + shift + one tile of rows, rounded up to a power of two) fits beside the tiles
+        const int shift = h.frame_length - h.overlap;
+        int ring_rows = 64;
+        while (ring_rows < h.frame_length + shift + HGA_TT + 2) ring_rows *= 2;
+        const size_t ring_bytes = (size_t)ring_rows * 16 * sizeof(double);
+        static const bool force_split = getenv("DSS_HGA_SPLIT") != nullptr;          // development: A/B against the 3-launch form
+        if (!force_split && ring_bytes <= 40 * 1024 && rows - h.overlap + HGA_TT <= (1 << 30) && h.overlap <= ring_rows) {
+            hipLaunchKernelGGL(hga_fused_kernel, dim3((unsigned)((pairs + 15) / 16)), dim3(256), ring_bytes, st, d_data, h.zi, h.rows,
+                               d_out, sos, h.S, h.C, n, h.nsec, row0, h.cap_rows, zero_rows, rows, W, h.overlap, h.fs, h.wl, h.ws,
+                               apply_log, ring_rows - 1);
+            DSS_HIP_CHECK(hipGetLastError());
+            return DSS_OK;
+        }
+    }
     hipLaunchKernelGGL(hga_filter_kernel, dim3((unsigned)((pairs + 15) / 16)), dim3(256), 0, st, d_data, h.zi, h.rows, sos,
                        h.S, h.C, n, h.nsec, row0, h.cap_rows, zero_rows);
     DSS_HIP_CHECK(hipGetLastError());
@@ -302,29 +467,40 @@ int dss_launch_log_power(const double *d_data, int T, int C, int sr, float wl, f
 }
 
 
-// Fused front end: column reorder + per-grid common average reference + channel selection, one lane per
-// (stream, sample).  The grid mean is a sequential sum in the reference's column order (numpy reduces the
-// Fortran-ordered fancy-index view column by column), then one division: bit-identical to the numpy chain.
-__global__ void __launch_bounds__(64)
+// Fused front end: column reorder + per-grid common average reference + channel selection.  A block stages FE_ROWS
+// consecutive (stream, sample) rows of the raw packet through LDS with coalesced loads (lanes across the c_raw columns;
+// the odd row length keeps column walks conflict-free), then one lane per (row, grid) runs the grid mean as the
+// SEQUENTIAL sum the reference's numpy expression performs (np.mean over a Fortran-ordered fancy-index copy adds one
+// column at a time) followed by one division, and finally lanes across the C output channels subtract and store
+// coalesced.  Bit-identical to the numpy chain (local/common.py:16-58,308-345).
+#define FE_ROWS 32
+__global__ void __launch_bounds__(256)
 hga_frontend_kernel(const double *__restrict__ raw, double *__restrict__ pre, int total, int c_raw, int C,
                     const int *__restrict__ src_col, const int *__restrict__ grid_of, int n_grids,
                     const int *__restrict__ comp_cols, const int *__restrict__ comp_off)
 {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const double *row = raw + (size_t)gid * c_raw;
-    double mean[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int g = 0; g < n_grids && g < 4; ++g) {
-        double sum = 0.0;
+    extern __shared__ __attribute__((aligned(16))) double fe_tile[];     // [FE_ROWS][c_raw], then [FE_ROWS][4] means
+    double *means = fe_tile + (size_t)FE_ROWS * c_raw;
+    const int tid = threadIdx.x;
+    const long row_base = (long)blockIdx.x * FE_ROWS;
+    const int nrows = (int)min((long)FE_ROWS, (long)total - row_base);
+    const double *src = raw + (size_t)row_base * c_raw;
+    for (int idx = tid; idx < nrows * c_raw; idx += 256) fe_tile[idx] = src[idx];       // rows are contiguous: fully coalesced
+    __syncthreads();
+    if (tid < nrows * n_grids) {
+        const int rr = tid / n_grids, g = tid - rr * n_grids;
+        const double *row = fe_tile + (size_t)rr * c_raw;
         const int a = comp_off[g], b2 = comp_off[g + 1];
+        double sum = 0.0;
         for (int k = a; k < b2; ++k) sum += row[comp_cols[k]];
-        mean[g] = sum / (double)(b2 - a);
+        means[rr * 4 + g] = sum / (double)(b2 - a);
     }
-    double *o = pre + (size_t)gid * C;
-    for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    for (int idx = tid; idx < nrows * C; idx += 256) {
+        const int rr = idx / C, c = idx - rr * C;
         const int g = grid_of[c];
-        const double v = row[src_col[c]];
-        o[c] = g >= 0 ? v - mean[g] : v;
+        const double v = fe_tile[(size_t)rr * c_raw + src_col[c]];
+        pre[((size_t)row_base + rr) * C + c] = g >= 0 ? v - means[rr * 4 + g] : v;
     }
 }
 
@@ -332,8 +508,10 @@ int dss_launch_hga_frontend(const double *d_raw, double *d_pre, int S, int n, in
                             const int *grid_of, int n_grids, const int *comp_cols, const int *comp_off, hipStream_t st)
 {
     const int total = S * n;
-    hipLaunchKernelGGL(hga_frontend_kernel, dim3((total + 63) / 64), dim3(64), 0, st, d_raw, d_pre, total, c_raw, C, src_col,
-                       grid_of, n_grids, comp_cols, comp_off);
+    const size_t lds = ((size_t)FE_ROWS * c_raw + FE_ROWS * 4) * sizeof(double);
+    if (lds > 64 * 1024 || n_grids > 4) { dss_set_error("front end: %d raw columns / %d grids exceed the tile", c_raw, n_grids); return DSS_EINVAL; }
+    hipLaunchKernelGGL(hga_frontend_kernel, dim3((total + FE_ROWS - 1) / FE_ROWS), dim3(256), lds, st, d_raw, d_pre, total, c_raw, C,
+                       src_col, grid_of, n_grids, comp_cols, comp_off);
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }
