@@ -189,6 +189,21 @@ def main():
     k_ms, f_ms = dec.kernel_ms(0), dec.kernel_ms(1)
     dec.enable_timing(False)
 
+    # the kernel a model with skewed sparsity lands on: the generic sample-rate kernel, same batch, N=1 only
+    generic = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        dec.enable_trace(16)                    # development switch: force the generic kernel (no tracing)
+        step(); torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        tg = (time.perf_counter() - tg) / 2
+        dec.enable_trace(0)
+        generic = {"kernel": "lpcnet_sample_generic_kernel", "ms_per_step": tg * 1e3, "value": B * FRAMES * FRAME / tg,
+                   "unit": "samples/s", "note": "GRU A blocks streamed from L2 every sample: what a model that exceeds the "
+                   "CU-resident kernel's per-row-group capacities (12 z/r, 28 h blocks) runs on; dss_lpcnet_model_info reports it"}
+
     # second half of BASELINE.json's metric: ECoG -> audio latency of the streaming mode (config 5), N=1 only
     latency = None
     if rank == 0 and world == 1 and not args.no_latency:
@@ -269,6 +284,7 @@ def main():
             "x_realtime": value / 16000.0, "samples_per_s_per_gpu": value / world,
             "roofline": roofline,
             "roofline_hbm_equiv": hbm,
+            "generic_kernel": generic,
             "cpu_baseline": cpu,
             "latency": latency,
         }

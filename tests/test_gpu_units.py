@@ -139,3 +139,32 @@ def test_asynchronous_synthesis_queue_file_contract(tmp_path, oracle):
         rate, pcm = wavread(tmp_path / f"{name}.wav")
         assert rate == 16000 and np.array_equal(pcm, oracle.lpcnet_utterance(m, synthetic_features(ord(name), n)))
     assert not (tmp_path / "bad.wav").exists()
+
+
+def test_replay_of_a_recorded_session(tmp_path, oracle):
+    """the logs decode_online.py leaves (raw packets, z-scored frames, decoded features) replayed through
+    the GPU path.  The 'recorded' session is produced here by the CPU chain (oracle transforms + filters + frame buffer),
+    written with the reference's logger format, and the replay must reproduce its frames bit for bit."""
+    from ecog_chain_oracle import ZScore, reference_chain
+    from dss_amd import formats, lpcnet, replay
+    from dss_amd.hga import reference_filters
+    lpcnet.load_model(synthetic_blob(0))
+    both, car, speech = reference_chain()
+    hg, fh, zi_hg, zi_fh = reference_filters(1000)
+    ex = oracle.extractor({"sos_hg": hg, "sos_fh": fh, "zi_hg": zi_hg, "zi_fh": zi_fh}, 64)
+    means, stds = np.full(64, 7.0), np.full(64, 1.5)
+    z = ZScore(means, stds)
+    raw = synthetic_ecog(4321, 40 * 12, 129)
+    with open(tmp_path / "log.raw.f64", "wb") as fr, open(tmp_path / "log.hga.f64", "wb") as fh_:
+        for pk in formats.iter_packets(raw, 40):
+            formats.append_stream_log(fr, formats.parse_packet(formats.build_packet(pk)).astype(np.float64) * 0 + pk)
+            formats.append_stream_log(fh_, z(ex.extract(speech(car(both(pk))))))
+    feats = synthetic_features(77, 9)
+    feats.tofile(tmp_path / "log.lpc.f32")
+    np.save(tmp_path / "stats.npy", np.stack([means, stds]))
+    rc = replay.main([str(tmp_path), "--normalization", str(tmp_path / "stats.npy"), "--wav", str(tmp_path / "out.wav")])
+    assert rc == 0                                                   # frames bit-identical to the recorded ones
+    from scipy.io.wavfile import read as wavread
+    rate, pcm = wavread(tmp_path / "out.wav")
+    m = oracle.lpcnet_model(synthetic_blob(0))
+    assert rate == 16000 and np.array_equal(pcm, oracle.lpcnet_utterance(m, feats))
