@@ -297,11 +297,16 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
             pos += 1 + grp_cnt[g];
             blk += grp_cnt[g];
         }
+        int zr_slots = 0;
+        for (int g = 0; g < 2 * groups_per_gate; ++g) zr_slots = std::max(zr_slots, grp_cnt[g]);
         for (int gate = 0; gate < 3; ++gate) {
             int slots = 0;
             for (int g = 0; g < groups_per_gate; ++g) slots = std::max(slots, grp_cnt[gate * groups_per_gate + g]);
-            std::vector<int> pos4((size_t)std::max(slots, 1) * NA, 0);
-            std::vector<float> w((size_t)std::max(slots, 1) * 4 * NA, 0.f);
+            // the generic kernel keeps 16 blocks in flight, unconditionally: z and r lists share one length (multiple of 8),
+            // the h list is a multiple of 16; the padding is zero blocks at input 0
+            slots = gate < 2 ? ((std::max(zr_slots, 1) + 7) & ~7) : ((std::max(slots, 1) + 15) & ~15);
+            std::vector<int> pos4((size_t)slots * NA, 0);
+            std::vector<float> w((size_t)slots * 4 * NA, 0.f);
             for (int unit = 0; unit < NA; ++unit) {
                 const int g = gate * groups_per_gate + unit / 8, r = unit & 7;
                 for (int sl = 0; sl < grp_cnt[g]; ++sl) {
