@@ -187,9 +187,6 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
         fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
         ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
     }
-#ifdef DSS_EXP_PRIO45
-    if constexpr (!HAS_FC) __builtin_amdgcn_s_setprio(DSS_EXP_PRIO45);
-#endif
     const float u2l_c = L.ulaw2lin[(HAS_FC ? 128 + tid : tid - 256) & 255];   // this lane's excitation candidate (waves 0, 1, 4, 5)
     const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
     const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;     // wave-uniform (kernel argument)
