@@ -7,18 +7,19 @@
 // already fills its registers and LDS with weights.  Here the weights are shared and the roles work on DIFFERENT
 // utterances at the same time.  Time is cut into slots; in slot s the utterance a = s mod U is "at the front":
 //
-//   waves 0..5 (role A)   z/r block products of a's coming sample, dual-FC of a's finished sample (waves 0..3) ->
-//                         A-wave rendezvous (LDS counter, no s_barrier) -> tree walk, speculated embedding indices,
-//                         embedding rows (L2) ... while those are in flight: the h-gate chain of b = a-1 (state written
-//                         last slot) and the speculation tables of c = a-2 ... -> z/r sums, gates, new GRU A state of a
-//   wave 6                GRU B inputs 0..191 of b (its GRU A state is one slot old); speculation candidates 0..63 of c
+//   waves 0..5 (role A)   dual-FC of a's finished sample (waves 0..3; waves 4, 5 take half of c's speculation instead) ->
+//                         "bits published" counter in LDS (no s_barrier) -> tree walk, speculated embedding indices,
+//                         embedding rows + conditioning (L2) ... while those are in flight: the h-gate chain of b = a-1
+//                         (state written last slot) ... -> z/r block products of a -> "old state read" counter -> z/r sums,
+//                         gates, new GRU A state of a
+//   wave 6                GRU B inputs 0..191 of b (its GRU A state is one slot old); speculation candidates 0..127 of c
 //   wave 7                GRU B inputs 192..383 + gates of c (wave 6 did its first half one slot ago); then the scalar
 //                         bookkeeping of b: tree walk, PCM / de-emphasis / history, next kiss99 thresholds, the inputs
 //                         of b's next speculation
 //   ONE workgroup barrier per slot.
 //
-// STATUS (round 2, measured on MI355X, tools/multi_time.py, 1024 x 1-s utterances): bit-exact, but 213 ms per batch against
-// 172 ms for four rounds of the latency kernel -- a slot takes ~8.2 k cycles where the design needs < 4.3 k to pay.
+// STATUS (round 2, measured on MI355X, tools/multi_time.py, 1024 x 1-s utterances): bit-exact, but 196 ms per batch against
+// 172 ms for four rounds of the latency kernel -- a slot takes ~7.8 k cycles where the design needs < 6.4 k to break even.
 // The counters (tools/prof_multi.sh) show why: VALU issue and LDS array are each busy only a third of the time; every
 // phase of a role-A wave (products, dual-FC, h chain, speculation, sums) is a dependent chain that waits on LDS / L2
 // round trips, and with all eight waves active those round trips are about twice as long as in the latency kernel, where
@@ -42,8 +43,9 @@ struct MuShared {                         // static LDS, shared by the utterance
     float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
     float tansig[208];
     float ulaw2lin[256];
-    int sync_cnt;                         // rendezvous counter of the six role-A waves (monotonic)
-    int pad[3];
+    int cnt_bits;                         // dual-FC waves that have published the front utterance's decision bits (monotonic)
+    int cnt_reads;                        // role-A waves that have finished reading the front utterance's old state (monotonic)
+    int pad[2];
 };
 
 struct MuUtt {                            // dynamic LDS, one per utterance, behind the h-gate block image
@@ -113,6 +115,28 @@ static_assert(sizeof(MuShared) % 16 == 0, "dynamic LDS must start 16-byte aligne
 
 // diagnostic build only: cycles per segment, accumulated per wave (never used for timing claims)
 #define MU_STAMP(SEG) if (STAMP) { const unsigned long long t_ = __builtin_readcyclecounter(); sacc[SEG] += t_ - tprev; tprev = t_; }
+
+// z/r block products with every state read in flight before the first multiplication: the product registers are the
+// landing zone of the loads (DSS_ZR_PRODUCTS waits for each pair of reads before it multiplies, which is free under the
+// GRU B shadow of the latency kernel and an LDS round trip per slot pair here)
+#define MU_ZR_PRODUCTS(XBUF)                                                                     \
+    {                                                                                            \
+        const char *xb = reinterpret_cast<const char *>(XBUF);                                   \
+        _Pragma("unroll") for (int s2 = 0; s2 < ZRC; s2 += 2) {                                  \
+            if (s2 >= nzr) break;                                                                \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                      \
+                PR[s2 + u] = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(s2 + u) * 16);     \
+                PR[ZRC + s2 + u] = *reinterpret_cast<const f32x4 *>(xb + DSS_ZR_COL(ZRL + s2 + u) * 16); \
+            }                                                                                    \
+        }                                                                                        \
+        _Pragma("unroll") for (int s2 = 0; s2 < ZRC; s2 += 2) {                                  \
+            if (s2 >= nzr) break;                                                                \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                      \
+                PR[s2 + u].lo = WZ[s2 + u].lo * PR[s2 + u].lo;             PR[s2 + u].hi = WZ[s2 + u].hi * PR[s2 + u].hi;             \
+                PR[ZRC + s2 + u].lo = WZ[ZRC + s2 + u].lo * PR[ZRC + s2 + u].lo; PR[ZRC + s2 + u].hi = WZ[ZRC + s2 + u].hi * PR[ZRC + s2 + u].hi; \
+            }                                                                                    \
+        }                                                                                        \
+    }
 
 // per-utterance schedule constants (identical in every wave: computed from the same global data)
 struct MuPlan {
@@ -195,10 +219,9 @@ __device__ __forceinline__ void mu_role_a(MuShared &S, MuUtt *UT, float *hblk_ld
         fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
         ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
     }
-    const float u2l_c = S.ulaw2lin[(HAS_FC ? 128 + tid : tid - 256) & 255];   // this lane's excitation candidate
+    const float u2l_c = S.ulaw2lin[(tid - 128) & 255];           // this lane's excitation candidate (waves 4, 5: 128..255)
     const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
     const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;
-    f32x4 PR[2 * ZRC];                                           // z/r block products of the front utterance's coming sample
     // h-gate chain of every utterance's FIRST sample (later ones run one slot after the state they need was written)
 #pragma unroll
     for (int j = 0; j < MU_MAX; ++j)
@@ -225,15 +248,8 @@ __device__ __forceinline__ void mu_role_a(MuShared &S, MuUtt *UT, float *hblk_ld
         const bool do_h = s >= 1 && kb >= 0 && kb + 1 < mu_pick(P.n, bq);
         const bool do_s = s >= 2 && kc >= 0 && kc + 1 < mu_pick(P.n, cq);
 
-        // ---- front utterance, before the rendezvous: conditioning, state, products, dual-FC ------------------
-        float cz = 0, cr = 0, ch = 0, st = 0, ahv = 0;
-        if (do_a1) {
-            const float *fo = b.frame_out + ((size_t)mu_pick(P.utt, a) * n_frames + mu_pick(P.f0, a) + k / DSS_FRAME_SIZE) * DSS_COND_STRIDE;
-            cz = fo[(unsigned)unit]; cr = fo[(unsigned)(NA + unit)]; ch = fo[(unsigned)(2 * NA + unit)];
-            st = UA.state_a[unit];
-            ahv = UA.ah[unit];
-            DSS_ZR_PRODUCTS(UA.state_a)
-        }
+        // ---- (1) dual-FC of the front utterance's finished sample (waves 0..3): its decision bits gate everybody's tree walk.
+        // Waves 4 and 5 have no dual-FC: they take their quarter of c's speculation meanwhile. ----------------------------------
         if constexpr (HAS_FC) {
             if (do_fc) {                                                            // sample_mdense, all nodes
                 const float thr_lv = UA.thr[level];
@@ -260,18 +276,20 @@ __device__ __forceinline__ void mu_role_a(MuShared &S, MuUtt *UT, float *hblk_ld
                 const unsigned long long mask = __ballot(bit);
                 if (lane == 0) { UA.bits[2 * wave] = (unsigned)mask; UA.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
             }
+            // relaxed: a wave's LDS operations execute in issue order, so the bits are written before the count moves
+            if (lane == 0) __hip_atomic_fetch_add(&S.cnt_bits, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (do_s) {
+                MuUtt &UC = UT[cq];
+                MU_SPECULATE(UC, tid - 128, u2l_c)               // wave 4: candidates 128..191, wave 5: 192..255
+            }
         }
-        // ---- rendezvous of the six role-A waves: every product / state read of the front utterance is done and its
-        // decision bits are written before anyone walks the tree or writes the new state --------------------------
         MU_STAMP(0)
-        if (lane == 0) __hip_atomic_fetch_add(&S.sync_cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        {
-            const int want = 6 * (s + 1);
-            while (__hip_atomic_load(&S.sync_cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
-                ;
-        }
+        // ---- (2) the decision bits of all four dual-FC waves, tree walk, speculated indices; embedding rows and this frame's
+        // conditioning are requested from L2 now and used in (5) -------------------------------------------------------------------
+        while (__hip_atomic_load(&S.cnt_bits, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (s + 1))
+            ;
         MU_STAMP(1)
-        // ---- embedding indices of the coming sample and its embedding rows (L2; used after the side work below) ----
         int si = 0, pi = 0, ei = 0;
         if (do_fc && do_a1) {
             int exc_;
@@ -284,24 +302,35 @@ __device__ __forceinline__ void mu_role_a(MuShared &S, MuUtt *UT, float *hblk_ld
         si = __builtin_amdgcn_readfirstlane(si); pi = __builtin_amdgcn_readfirstlane(pi); ei = __builtin_amdgcn_readfirstlane(ei);
         typedef float f32x3 __attribute__((ext_vector_type(3)));
         f32x3 es = {0, 0, 0}, ep = {0, 0, 0}, ee = {0, 0, 0};
+        float cz = 0, cr = 0, ch = 0;
         if (do_a1) {
+            const float *fo = b.frame_out + ((size_t)mu_pick(P.utt, a) * n_frames + mu_pick(P.f0, a) + k / DSS_FRAME_SIZE) * DSS_COND_STRIDE;
+            cz = fo[(unsigned)unit]; cr = fo[(unsigned)(NA + unit)]; ch = fo[(unsigned)(2 * NA + unit)];
             es = *reinterpret_cast<const f32x3 *>(m.embed_lane[0] + ((unsigned)si * NA + (unsigned)tid) * 3);
             ep = *reinterpret_cast<const f32x3 *>(m.embed_lane[1] + ((unsigned)pi * NA + (unsigned)tid) * 3);
             ee = *reinterpret_cast<const f32x3 *>(m.embed_lane[2] + ((unsigned)ei * NA + (unsigned)tid) * 3);
         }
         MU_STAMP(2)
-        // ---- side work for the utterances behind the front (fills the L2 latency of the loads above) -------------
+        // ---- (3) side work under the L2 latency: h-gate chain of b (its state was written last slot).  The product registers
+        // are not live yet, which is what keeps this role inside 256 VGPRs without spill reloads in the slot loop. ------------
         if (do_h) {
             float *ah_dst = UT[bq].ah;
             DSS_H_CHAIN(UT[bq].state_a)                          // h-gate chain of b's coming sample
         }
         MU_STAMP(3)
-        if (do_s && (wave == 5 || wave < 2)) {
-            MuUtt &UC = UT[cq];
-            MU_SPECULATE(UC, HAS_FC ? 128 + tid : tid - 256, u2l_c)
+        // ---- (4) front utterance: old state, z/r block products; then "my reads of its state are done" ------------------------
+        f32x4 PR[2 * ZRC];                                       // z/r block products of the front utterance's coming sample
+        float st = 0, ahv = 0;
+        if (do_a1) {
+            st = UA.state_a[unit];
+            ahv = UA.ah[unit];
+            MU_ZR_PRODUCTS(UA.state_a)
         }
+        if (lane == 0) __hip_atomic_fetch_add(&S.cnt_reads, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         MU_STAMP(4)
-        // ---- the front utterance's sample: z/r sums, gates, new state -----------------------------------------------
+        // ---- (5) the front utterance's sample: z/r sums, gates, new state (nobody overwrites the state another wave still reads)
+        while (__hip_atomic_load(&S.cnt_reads, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 6 * (s + 1))
+            ;
         if (do_a1) {
             float az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
             float ar = rbr + dgr * st;
@@ -359,7 +388,7 @@ lpcnet_sample_multi_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__
     for (int q = tid; q < NB * NB3; q += 512) S.gb_wrec[q] = m.gru_b_w_rec[q];
     if (tid < 201) S.tansig[tid] = m.tansig[tid];
     if (tid < 256) S.ulaw2lin[tid] = m.ulaw2lin[tid];
-    if (tid == 0) S.sync_cnt = 0;
+    if (tid == 0) { S.cnt_bits = 0; S.cnt_reads = 0; }
     for (int j = 0; j < U; ++j) {
         const int u = blockIdx.x * U + j;
         if (u < n_utts) {
@@ -393,6 +422,7 @@ lpcnet_sample_multi_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__
             WB[j].y = m.gb_w_lane[(size_t)(2 * j + 1) * 64 + lane];
         }
         const float gbb0 = m.gru_b_bias[row];
+        __builtin_amdgcn_s_setprio(1);          // the youngest waves of the workgroup lose every issue arbitration otherwise
         __syncthreads();                                             // prologue barrier
         unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = STAMP ? __builtin_readcyclecounter() : 0;
         int a = 0, k = 0;
@@ -413,6 +443,7 @@ lpcnet_sample_multi_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__
             if (s >= 2 && kc >= 0 && kc + 1 < mu_pick(P.n, cq)) {
                 MuUtt &UC = UT[cq];
                 MU_SPECULATE(UC, lane, S.ulaw2lin[lane])                               // candidates 0..63
+                MU_SPECULATE(UC, 64 + lane, S.ulaw2lin[64 + lane])                     // ... and 64..127
             }
             MU_STAMP(1)
             __syncthreads();                                                            // slot barrier
@@ -472,6 +503,7 @@ lpcnet_sample_multi_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__
             UJ.rng[0] = rng.z; UJ.rng[1] = rng.w; UJ.rng[2] = rng.jsr; UJ.rng[3] = rng.jcong;
         }
     }
+    __builtin_amdgcn_s_setprio(1);
     __syncthreads();                                                 // prologue barrier
     unsigned long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = STAMP ? __builtin_readcyclecounter() : 0;
     int a = 0, k = 0;

@@ -18,7 +18,7 @@ raw = np.empty((F * 160,), np.float32)
 _lib.check(gpu._L.dss_lpcnet_batch_tap(gpu._h, 0, 4, raw.ctypes.data, raw.size))
 slots = U * ((F - 2) * 160 + 1) + 2
 st = raw[:64].reshape(8, 8) / slots
-namesA = ["pre(cond,prod,FC)", "rendezvous", "walk+emb issue", "h chain", "speculation", "sums+gates", "barrier wait"]
+namesA = ["FC | spec(4,5)", "wait bits", "walk+emb issue", "h chain", "products", "wait reads+sums+gates", "barrier wait"]
 for w in range(6):
     print(f"wave {w}: " + "  ".join(f"{namesA[q]}={st[w, q]:7.1f}" for q in range(7)), f" total {st[w, :7].sum():.0f}")
 print("wave 6: " + "  ".join(f"{n}={st[6, q]:7.1f}" for q, n in enumerate(["chain half 1", "speculation", "barrier wait"])), f" total {st[6, :3].sum():.0f}")
