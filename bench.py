@@ -215,7 +215,7 @@ def main():
                    "ticks": int(args.latency_ticks), "stream_seconds": args.latency_ticks * 0.04,
                    "config": "128 concurrent 64-ch ECoG streams, one 40-sample packet per stream per tick (4 frames): host "
                              "packet in -> HGA -> BiLSTM (chunk-wise, VAD gating off) -> LPCNet -> 640 int16 samples per "
-                             "stream back on the host; structural floor of the reference (0.55 s + whole-segment "
+                             "stream back on the host (steady-state tick replayed from a captured HIP graph); structural floor of the reference (0.55 s + whole-segment "
                              "synthesis) not included"}
 
     # HBM traffic and issue counters of the dominant kernel per launch: PMC counters cannot be read from inside this

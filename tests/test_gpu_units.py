@@ -117,6 +117,13 @@ def test_streaming_pipeline_config5():
     assert nxt.shape == (S, 640) and nxt.dtype == np.int16     # then 4 frames = 40 ms of audio per packet
     lat = sp.measure_latency(20)
     assert np.isfinite(lat).all() and np.percentile(lat, 50) < 40.0   # must keep up with the 40 ms packet cadence
+    # the steady-state tick replayed from a captured HIP graph gives the same PCM as eager launches
+    a, b2 = StreamingPipeline(16, use_graph=True), StreamingPipeline(16, use_graph=False)
+    rng = np.random.default_rng(5)
+    for k in range(6):
+        pk = rng.standard_normal((16, 40, 64)) * 50
+        assert np.array_equal(a.push(pk), b2.push(pk)), k
+    assert a._graph is not None or a._graph_failed
 
 
 def test_asynchronous_synthesis_queue_file_contract(tmp_path, oracle):
