@@ -201,8 +201,10 @@ def main():
         tg = (time.perf_counter() - tg) / 2
         dec.enable_trace(0)
         generic = {"kernel": "lpcnet_sample_generic_kernel", "ms_per_step": tg * 1e3, "value": B * FRAMES * FRAME / tg,
-                   "unit": "samples/s", "note": "GRU A blocks streamed from L2 every sample: what a model that exceeds the "
-                   "CU-resident kernel's per-row-group capacities (12 z/r, 28 h blocks) runs on; dss_lpcnet_model_info reports it"}
+                   "unit": "samples/s", "note": "GRU A blocks streamed from L2 every sample: what a model runs on whose sparsity is "
+                   "too skewed even for the CU-resident kernel's tail paths (over 16 z/r blocks of a row group beyond its register "
+                   "slots, over 64 h blocks, or an LDS image over 138752 B); dss_lpcnet_model_info reports it, "
+                   "profiles/r2_model_fit.txt has the steps in between"}
 
     # second half of BASELINE.json's metric: ECoG -> audio latency of the streaming mode (config 5), N=1 only
     latency = None

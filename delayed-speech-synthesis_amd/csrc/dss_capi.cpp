@@ -336,13 +336,14 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
             zmax = std::max(zmax, std::max(cnt[g], cnt[G + g]));
             hmax = std::max(hmax, cnt[2 * G + g]);
         }
-        if (zmax > DSS_ZRC || hmax > DSS_HC) fast_ok = 0;
+        if (hmax > DSS_HC + DSS_HX) fast_ok = 0;
         // Two independent lane assignments, both "8 row groups per wave":
         //  * h-gate chains (LDS resident): groups sorted by h block count, so each wave's loop length (its
-        //    largest group) is close to what all its groups need and the LDS image stays small;
+        //    largest group) is close to what all its groups need;
         //  * z/r chains (register resident): groups sorted by max(z, r) block count.  The 16 heaviest groups go to
-        //    waves 4 and 5, whose code path carries no dual-FC weights and therefore has room for all DSS_ZRC register
-        //    slots per gate; waves 0..3 run the 8-slot instantiation, so the other 32 groups must fit 8 slots.
+        //    waves 4 and 5, whose code path carries no dual-FC weights and therefore has room for zr_cap register
+        //    slots per gate; waves 0..3 run the 8-slot instantiation.  Blocks beyond a wave's register slots (models
+        //    with skewed sparsity) stay in idx order behind them as "tail" records in LDS.
         // Both the h chain and the z/r block products run between barriers B and C, under the GRU B relay; waves 4
         // and 5 also run the speculation there, so they get the lightest h chains, and among waves 0..3 the heavier
         // z/r groups go with the lighter h chains.
@@ -353,10 +354,17 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         std::stable_sort(order_zr.begin(), order_zr.end(), [&](int a, int b2) {
             return std::max(cnt[a], cnt[G + a]) > std::max(cnt[b2], cnt[G + b2]);
         });
+        // Register slots per gate on waves 4, 5.  A model that fits the register slots as it is runs the 10-slot
+        // instantiation (no spills) or, with 11 or 12 blocks in some group, the 12-slot one (22 spilled registers, ~4 %
+        // slower).  Any other model runs the 10-slot layout with tails: measured faster than 12 slots + tails
+        // (tools/model_fit.py), the spills cost more than the two extra tail blocks.
+        const int zr17 = std::max(cnt[order_zr[16]], cnt[G + order_zr[16]]);      // heaviest group that lands on waves 0..3
+        const bool plain = zmax <= DSS_ZRC && zr17 <= 8 && hmax <= DSS_HC;
+        const int zr_cap = (plain && zmax > 10) ? DSS_ZRC : 10;
         static const int rank_wave_h[6] = {0, 1, 3, 2, 5, 4};
         static const int rank_wave_zr[6] = {4, 5, 2, 3, 1, 0};
-        std::vector<int> unit_of(NA, 0), unit_h(NA, 0), wave_nh(8, 0), wave_hoff(8, 0), wave_nzr(8, 0), grp_h(G, 0), grp_zr(G, 0);
-        int hfloats = 0;
+        std::vector<int> unit_of(NA, 0), unit_h(NA, 0), wave_nh(8, 0), grp_hoff(G, 0), wave_nzr(8, 0), wave_nzt(8, 0), grp_h(G, 0), grp_zr(G, 0);
+        int hfloats = 0, ext = 0;
         for (int rk = 0; rk < 6 && fast_ok; ++rk) {
             int nh = 0, nzr = 0;
             for (int q = 0; q < 8; ++q) {
@@ -365,15 +373,49 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
                 nh = std::max(nh, cnt[2 * G + order_h[rk * 8 + q]]);
                 nzr = std::max(nzr, std::max(cnt[order_zr[rk * 8 + q]], cnt[G + order_zr[rk * 8 + q]]));
             }
+            const int cap = rank_wave_zr[rk] < 4 ? 8 : zr_cap;
             wave_nh[rank_wave_h[rk]] = (nh + 1) & ~1;       // the kernel tests for the end of a list every 2 slots
-            wave_nzr[rank_wave_zr[rk]] = (nzr + 1) & ~1;
-            if (rank_wave_zr[rk] < 4 && nzr > 8) fast_ok = 0;     // waves 0..3: 8 register slots per gate
+            wave_nzr[rank_wave_zr[rk]] = std::min((nzr + 1) & ~1, cap);
+            wave_nzt[rank_wave_zr[rk]] = std::max(0, nzr - cap);
+            if (nzr - cap > DSS_ZR_TAIL) fast_ok = 0;
+            if (nzr > cap || nh > DSS_HC) ext = 1;
         }
-        for (int wv = 0; wv < 6 && fast_ok; ++wv) {
-            wave_hoff[wv] = hfloats;
-            // one extra 128-byte record per group: consecutive groups then start 32 banks apart, which makes
-            // the 16-lane phases of a wave's ds_read_b128 of its block records conflict-free
-            hfloats += 8 * (wave_nh[wv] + 1) * 32;
+        // The h-gate image: every row group's own records back to back (128 bytes = [8 rows][4 inputs] per block), no
+        // padding to the wave's longest list.  A wave still runs wave_nh slots on all its lanes: a lane whose group is
+        // shorter reads on into the next group's records and multiplies them by "column 96", four zeros behind the
+        // state vector, so the extra terms are +-0.  One spare record goes between two groups of a wave whenever
+        // they would otherwise start an even number of records apart: 8-lane groups that start 32 banks apart keep
+        // the wave's ds_read_b128 of its block records conflict-free.
+        int hend = 0;
+        for (int wv = 0; wv < 6 && fast_ok; ++wv)
+            for (int q = 0; q < 8; ++q) {
+                if (q && (((hfloats - grp_hoff[wv * 8 + q - 1]) / 32) & 1) == 0) hfloats += 32;
+                grp_hoff[wv * 8 + q] = hfloats;
+                hfloats += cnt[2 * G + grp_h[wv * 8 + q]] * 32;
+                hend = std::max(hend, grp_hoff[wv * 8 + q] + wave_nh[wv] * 32);
+            }
+        hfloats = std::max(hfloats, hend);                  // the last groups' over-reads stay inside the image
+        // Extended paths (models with skewed sparsity only): behind the h records, the z and r tail lists of every
+        // group of the z/r assignment (same over-read convention), then a table
+        //   int   tail_off[48][2]                float offset of the group's z list and of its r list
+        //   uint8 tail_col[48][2][DSS_ZR_TAIL]   block column of every tail slot (96 = unused)
+        //   uint8 hx_col[48][DSS_HX]             block column of h slots DSS_HC.. of the group of the h assignment
+        const int ext_tab_floats = (G * 2 * 4 + G * 2 * DSS_ZR_TAIL + G * DSS_HX) / 4;
+        std::vector<int> tail_off(G * 2, 0);
+        int ext_tab = 0;
+        if (fast_ok && ext) {
+            int tend = hfloats;
+            for (int wv = 0; wv < 6; ++wv)
+                for (int q = 0; q < 8; ++q)
+                    for (int gate = 0; gate < 2; ++gate) {
+                        const int cap = wv < 4 ? 8 : zr_cap, n = cnt[gate * G + grp_zr[wv * 8 + q]];
+                        tail_off[(wv * 8 + q) * 2 + gate] = hfloats;
+                        tend = std::max(tend, hfloats + wave_nzt[wv] * 32);
+                        hfloats += std::max(0, n - cap) * 32;
+                    }
+            hfloats = std::max(hfloats, tend);
+            ext_tab = hfloats;
+            hfloats += ext_tab_floats;
         }
         if ((size_t)hfloats * sizeof(float) > DSS_HBLK_BYTES) fast_ok = 0;
         std::vector<float> zr_w((size_t)2 * DSS_ZRC * 4 * NA, 0.f), hblk((size_t)std::max(hfloats, 4), 0.f);
@@ -384,13 +426,19 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
                 {
                     const int grp = grp_zr[wv * 8 + q];
                     unit_of[tid] = grp * 8 + r;
+                    const int cap = wv < 4 ? 8 : zr_cap;
                     for (int gate = 0; gate < 2; ++gate) {
                         const int g = gate * G + grp;
-                        for (int sl = 0; sl < cnt[g]; ++sl) {
+                        for (int sl = 0; sl < std::min(cnt[g], cap); ++sl) {
                             const int s2 = gate * DSS_ZRC + sl;
                             const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
                             for (int k = 0; k < 4; ++k) zr_w[((size_t)s2 * 4 + k) * NA + tid] = wb[k * 8 + r];
                             zr_col[(size_t)(s2 >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (s2 & 3));
+                        }
+                        for (int sl = cap; sl < cnt[g]; ++sl) {              // tail: LDS records, columns in the table
+                            const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                            float *rec = hblk.data() + tail_off[(wv * 8 + q) * 2 + gate] + (size_t)(sl - cap) * 32 + r * 4;
+                            for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
                         }
                     }
                 }
@@ -399,14 +447,38 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
                     unit_h[tid] = grp * 8 + r;
                     for (int sl = 0; sl < cnt[g]; ++sl) {
                         const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                        float *rec = hblk.data() + wave_hoff[wv] + ((size_t)q * (wave_nh[wv] + 1) + sl) * 32 + r * 4;
+                        float *rec = hblk.data() + grp_hoff[wv * 8 + q] + (size_t)sl * 32 + r * 4;
                         for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
-                        h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
+                        if (sl < DSS_HC) h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
                     }
+                    for (int sl = cnt[g]; sl < DSS_HC; ++sl) h_col[(size_t)(sl >> 2) * NA + tid] |= 96u << (8 * (sl & 3));
                 }
             }
+        if (fast_ok && ext) {
+            int *toff = reinterpret_cast<int *>(hblk.data() + ext_tab);
+            unsigned char *tcol = reinterpret_cast<unsigned char *>(toff + G * 2);
+            unsigned char *hxc = tcol + (size_t)G * 2 * DSS_ZR_TAIL;
+            memset(tcol, 96, (size_t)G * 2 * DSS_ZR_TAIL + (size_t)G * DSS_HX);
+            for (int wv = 0; wv < 6; ++wv)
+                for (int q = 0; q < 8; ++q) {
+                    const int cap = wv < 4 ? 8 : zr_cap;
+                    for (int gate = 0; gate < 2; ++gate) {
+                        const int g = gate * G + grp_zr[wv * 8 + q];
+                        toff[(wv * 8 + q) * 2 + gate] = tail_off[(wv * 8 + q) * 2 + gate];
+                        for (int sl = cap; sl < cnt[g]; ++sl)
+                            tcol[((size_t)(wv * 8 + q) * 2 + gate) * DSS_ZR_TAIL + (sl - cap)] = (unsigned char)(v.gru_a_idx[start[g] + sl] / 4);
+                    }
+                    const int gh = 2 * G + grp_h[wv * 8 + q];
+                    for (int sl = DSS_HC; sl < cnt[gh]; ++sl)
+                        hxc[(size_t)(wv * 8 + q) * DSS_HX + (sl - DSS_HC)] = (unsigned char)(v.gru_a_idx[start[gh] + sl] / 4);
+                }
+        }
         m.fast_ok = fast_ok;
         m.nzr_max = (zmax + 1) & ~1;
+        m.zr_cap = zr_cap;
+        m.hmax = hmax;
+        m.ext = fast_ok ? ext : 0;
+        m.ext_tab = ext_tab;
         m.hblk_floats = hfloats;
         int *di; float *df; unsigned *du;
         rc = dev_upload<int>(unit_of.data(), unit_of.size(), &di); if (rc) return rc; m.unit_of = di;
@@ -423,8 +495,9 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         }
         rc = dev_upload<int>(unit_h.data(), unit_h.size(), &di); if (rc) return rc; m.unit_h = di;
         rc = dev_upload<int>(wave_nh.data(), wave_nh.size(), &di); if (rc) return rc; m.wave_nh = di;
-        rc = dev_upload<int>(wave_hoff.data(), wave_hoff.size(), &di); if (rc) return rc; m.wave_hoff = di;
+        rc = dev_upload<int>(grp_hoff.data(), grp_hoff.size(), &di); if (rc) return rc; m.grp_hoff = di;
         rc = dev_upload<int>(wave_nzr.data(), wave_nzr.size(), &di); if (rc) return rc; m.wave_nzr = di;
+        rc = dev_upload<int>(wave_nzt.data(), wave_nzt.size(), &di); if (rc) return rc; m.wave_nzt = di;
         rc = dev_upload<float>(zr_w.data(), zr_w.size(), &df); if (rc) return rc; m.zr_w = df;
         rc = dev_upload<unsigned>(zr_col.data(), zr_col.size(), &du); if (rc) return rc; m.zr_col = du;
         rc = dev_upload<unsigned>(h_col.data(), h_col.size(), &du); if (rc) return rc; m.h_col = du;
@@ -668,7 +741,7 @@ extern "C" int dss_lpcnet_model_info(int *fast_path, int *zr_slots_max, int *h_s
         long pos = 0;
         for (int g = 0; g < 3 * G; ++g) { const int c = v.gru_a_idx[pos]; if (g >= 2 * G) hmax = std::max(hmax, c); pos += 1 + c; }
     }
-    if (fast_path) *fast_path = m->fast_ok;
+    if (fast_path) *fast_path = m->fast_ok ? (m->ext ? 2 : 1) : 0;
     if (zr_slots_max) *zr_slots_max = m->nzr_max;
     if (h_slots_max) *h_slots_max = hmax;
     if (h_lds_bytes) *h_lds_bytes = m->hblk_floats * 4;

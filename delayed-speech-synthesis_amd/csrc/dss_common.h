@@ -20,11 +20,16 @@
 #define DSS_FC_OUT 256
 #define DSS_COND_STRIDE (3 * DSS_GRU_A + 3 * DSS_GRU_B + DSS_LPC_ORDER)   // 1216 floats per frame
 #define DSS_FEATURES_DELAY 2
-// Capacities of the CU-resident sample-rate kernel (lpcnet_sample.hip).  A model that exceeds any of them
-// (or whose h-gate block image does not fit DSS_HBLK_BYTES of LDS) runs on the generic kernel instead.
+// Capacities of the CU-resident sample-rate kernel (lpcnet_sample.hip).  Row groups with more z/r blocks than their
+// wave has register slots keep the surplus ("tail", in idx order behind the register slots) as LDS records next to the
+// h-gate image, and h lists longer than DSS_HC take the column ids of the further slots from LDS: slower per extra block,
+// same results.  A model that exceeds the outer limits (DSS_ZR_TAIL, DSS_HX, or whose LDS image does not fit
+// DSS_HBLK_BYTES) runs on the generic kernel instead.
 #define DSS_ZRC 12            // register slots per lane for the z-gate and for the r-gate 8x4 blocks
-#define DSS_HC 28             // max h-gate blocks per row group (LDS resident; column ids in 7 VGPRs)
-#define DSS_HBLK_BYTES 137728  // dynamic LDS left after the kernel's static 24 KB (160 KB per CU)
+#define DSS_HC 28             // h-gate slots per row group whose column ids sit in VGPRs (7)
+#define DSS_ZR_TAIL 16        // max z (and r) blocks per row group beyond its wave's register slots
+#define DSS_HX 36             // max h-gate blocks per row group beyond DSS_HC
+#define DSS_HBLK_BYTES 138752  // dynamic LDS left after the kernel's static 24.5 KB (160 KB per CU)
 
 void dss_set_error(const char *fmt, ...);
 
@@ -71,17 +76,22 @@ struct DssModelDev {
     const double *lag_window;     // [17] 1 - 6e-5*i*i
     // register-resident layout of the sample-rate kernel (lpcnet_sample.hip)
     int fast_ok;                  // 1 when the model fits the capacities above
-    int nzr_max;                  // max(z blocks, r blocks) over all row groups, rounded up to even
+    int nzr_max;                  // max(z blocks, r blocks) over all row groups, rounded up to even (reporting)
+    int zr_cap;                   // register slots per gate of waves 4, 5: 10 or 12 (selects the instantiation)
+    int hmax;                     // max h blocks over all row groups (reporting)
+    int ext;                      // 1 when the model uses z/r tails or h slots beyond DSS_HC (latency kernel only)
+    int ext_tab;                  // float offset inside hblk of the tables the extended paths read (see dss_capi.cpp)
     int hblk_floats;              // size of hblk
     const int *unit_of;           // [384] lane of waves 0..5 -> GRU A unit whose z and r chains it runs
     const int *unit_h;            // [384] lane of waves 0..5 -> GRU A unit whose h-gate chain it runs
     const int *wave_nh;           // [8]   per wave: h-gate slots (even), [6],[7] unused
-    const int *wave_hoff;         // [8]   per wave: float offset of its block records inside hblk
-    const int *wave_nzr;          // [8]   per wave: z/r slots actually used (even)
+    const int *grp_hoff;          // [48]  per (wave, lane / 8): float offset of that row group's block records inside hblk
+    const int *wave_nzr;          // [8]   per wave: z/r register slots actually used (even)
+    const int *wave_nzt;          // [8]   per wave: z/r tail slots (LDS records), max over its groups and both gates
     const float *zr_w;            // [2*DSS_ZRC][4][384] z then r block weights per lane slot, zero padded
     const unsigned *zr_col;       // [2*DSS_ZRC/4][384]  four 8-bit block column ids (pos/4) per word
     const unsigned *h_col;        // [DSS_HC/4][384]     same for the h-gate slots of the lane's row group
-    const float *hblk;            // LDS image: per wave, per group slot q (8): nh+1 records of [8 rows][4]
+    const float *hblk;            // LDS image: one list of [8 rows][4] records per row group, lists back to back (see dss_capi.cpp)
     const float *gb_w_lane;       // [384][64] GRU B input weights, input-major, lane = row (rows 48..63 zero)
 };
 

@@ -27,6 +27,22 @@
 // and the library is built with -ffp-contract=off, so results are bit-identical to the scalar C path.
 #include <mutex>
 
+// h-gate slots DSS_HC.. of a long list: column ids from the table behind the LDS image instead of registers, one chunk of
+// two blocks per trip (a dependent LDS round trip for the ids: slower per block than the register-id loop, same sums)
+#define DSS_H_TAIL                                                                               \
+    if constexpr (EXT) if (nh > HC) {                                                            \
+        const unsigned char *hx = reinterpret_cast<const unsigned char *>(hblk_lds + m.ext_tab) + \
+                                  (NA / 8) * 2 * 4 + (NA / 8) * 2 * DSS_ZR_TAIL + (tid >> 3) * DSS_HX; \
+        for (int s = HC; s < nh; s += 2) {                                                       \
+            const unsigned c0 = hx[s - HC], c1 = hx[s - HC + 1];                                 \
+            f32x4 HT[4];                                                                         \
+            HT[0] = *reinterpret_cast<const f32x4 *>(hw + s * 128);                              \
+            HT[1] = *reinterpret_cast<const f32x4 *>(hw + (s + 1) * 128);                        \
+            HT[2] = *reinterpret_cast<const f32x4 *>(xbase + c0 * 16);                           \
+            HT[3] = *reinterpret_cast<const f32x4 *>(xbase + c1 * 16);                           \
+            DSS_H_MAC(HT)                                                                        \
+        }                                                                                        \
+    }
 #include "lpcnet_sample_common.h"
 
 #define GBH6 208                          // GRU B inputs whose weights sit in wave 6's VGPRs (0..207)
@@ -37,7 +53,8 @@
 #define GBP 48                            // ... of wave 7's inputs, the first GBP are multiplied while it waits for wave 6
 #endif
 struct SampleLds {
-    float state_a[2][NA];                 // double-buffered GRU A state
+    float state_a[2][NA + 4];             // double-buffered GRU A state; "column 96" of either buffer is four zeros: the
+                                          //   input of the h-gate slots a row group does not use (see DSS_H_CHAIN)
     float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
     float gb_wl[NB3 * GBL_STRIDE];        // GRU B input weights of the last GBHL inputs, row-major
     float tansig[208];
@@ -146,7 +163,7 @@ struct SampleLds {
 //   waves 4..5  no dual-FC, all Z slots -- the host gives them the row groups with the most z/r blocks.
 // Keeping the two apart is what keeps either under the 256-VGPR budget without spill reloads in the sample loop.
 // =====================================================================================================
-template <bool TRACE, bool STAMP, int Z, bool HAS_FC>
+template <bool TRACE, bool STAMP, int Z, bool HAS_FC, bool EXT>
 __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const DssModelDev &m, const DssBatchDev &b,
                                            int n_frames, int utt, int slot, int nf, int fc0, int tid, int wave, int lane)
 {
@@ -154,8 +171,8 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
     const int uh = m.unit_h[tid];                                // h-gate chain of this (other) unit
     const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
     const int nzr = __builtin_amdgcn_readfirstlane(m.wave_nzr[wave]);
-    const char *hw = reinterpret_cast<const char *>(hblk_lds + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
-                     ((lane >> 3) * (nh + 1) * 128 + (lane & 7) * 16);
+    const int nzt = EXT ? __builtin_amdgcn_readfirstlane(m.wave_nzt[wave]) : 0;   // z/r blocks beyond the register slots (LDS records)
+    const char *hw = reinterpret_cast<const char *>(hblk_lds + m.grp_hoff[tid >> 3]) + (lane & 7) * 16;
     f32x4 WZ[2 * ZRC];                                           // [0,ZRC) z slots, [ZRC,2ZRC) r slots
     unsigned PZ[(2 * ZRL + 3) / 4], PH[HC / 4];
 #pragma unroll
@@ -261,6 +278,25 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                         az += PR[s2 + u].w; ar += PR[ZRC + s2 + u].w;
                     }
                 }
+                if constexpr (EXT) if (nzt) {
+                    // models with skewed sparsity: the row group's blocks beyond its register slots, still in idx order --
+                    // weights from the tail records behind the h-gate image, columns from the table, state of this sample
+                    const int *toff = reinterpret_cast<const int *>(hblk_lds + m.ext_tab) + (tid >> 3) * 2;
+                    const unsigned char *tc = reinterpret_cast<const unsigned char *>(hblk_lds + m.ext_tab) + (NA / 8) * 2 * 4 +
+                                              (tid >> 3) * 2 * DSS_ZR_TAIL;
+                    const char *tz = reinterpret_cast<const char *>(hblk_lds + toff[0]) + (lane & 7) * 16;
+                    const char *tr = reinterpret_cast<const char *>(hblk_lds + toff[1]) + (lane & 7) * 16;
+                    const char *xb = reinterpret_cast<const char *>(L.state_a[cur]);
+                    for (int s = 0; s < nzt; ++s) {
+                        const f32x4 wz = *reinterpret_cast<const f32x4 *>(tz + s * 128);
+                        const f32x4 wr = *reinterpret_cast<const f32x4 *>(tr + s * 128);
+                        const f32x4 xz = *reinterpret_cast<const f32x4 *>(xb + (unsigned)tc[s] * 16);
+                        const f32x4 xr = *reinterpret_cast<const f32x4 *>(xb + (unsigned)tc[DSS_ZR_TAIL + s] * 16);
+                        const f32x2 pz0 = wz.lo * xz.lo, pz1 = wz.hi * xz.hi, pr0 = wr.lo * xr.lo, pr1 = wr.hi * xr.hi;
+                        az += pz0.x; ar += pr0.x; az += pz0.y; ar += pr0.y;
+                        az += pz1.x; ar += pr1.x; az += pz1.y; ar += pr1.y;
+                    }
+                }
                 if (recur_first) { az = gz + az; ar = gr + ar; }
                 if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
                 float z, r;
@@ -344,7 +380,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
 // RAGGED: rows name their decoder slot and frame count (b.slot_of / b.count_of).  A separate instantiation, so the
 // uniform form keeps its register allocation (the two extra live scalars cost 1.3 % there); the trace build always
 // honours the lists.
-template <bool TRACE, bool STAMP, int Z, bool RAGGED>
+template <bool TRACE, bool STAMP, int Z, bool RAGGED, bool EXT>
 __global__ void __launch_bounds__(512)
 lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restrict__ pcm_out)
 {
@@ -370,15 +406,16 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     if (tid < 201) L.tansig[tid] = m.tansig[tid];
     if (tid < 256) L.ulaw2lin[tid] = m.ulaw2lin[tid];
     if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)slot * NA + tid];
+    if (tid < 8) L.state_a[tid >> 2][NA + (tid & 3)] = 0.f;
     if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)slot * NB + tid];
     if (tid == 0) L.gb_flag = 0;
     const int fc0 = b.fc0[utt];
     __syncthreads();
 
     if (wave < 4) {
-        dss_role_a<TRACE, STAMP, (Z < 8 ? Z : 8), true>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane);
+        dss_role_a<TRACE, STAMP, (Z < 8 ? Z : 8), true, EXT>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane);
     } else if (wave < 6) {
-        dss_role_a<TRACE, STAMP, Z, false>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane);
+        dss_role_a<TRACE, STAMP, Z, false, EXT>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane);
     } else if (wave == 6) {
         // =====================================================================================================
         // role B1: GRU B over inputs 0..207, lane = row (0..15 z, 16..31 r, 32..47 h)
@@ -631,7 +668,7 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
     }
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
     // two register-slot capacities are compiled: 10 per gate (no spills) and 12 (a few spilled registers)
-    const bool z10 = m.nzr_max <= 10;
+    const bool z10 = m.zr_cap <= 10;
     static std::mutex attr_mu;                  // states on different devices may launch from different threads
     static unsigned long long attr_set = 0;     // per device: the attribute belongs to the device's code object
     int dev = 0;
@@ -640,26 +677,37 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
     std::lock_guard<std::mutex> attr_lk(attr_mu);
     if (!(attr_set >> (dev & 63) & 1)) {      // one workgroup uses (almost) the whole 160 KB of the CU
 #define DSS_SET_ATTR(K) DSS_HIP_CHECK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_HBLK_BYTES))
-        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, false>)); DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, false>));
-        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, true>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, true>));
-        DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 10, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 12, false>));
-        DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 10, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 12, false>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, false, false>)); DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, false, false>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, true, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 12, true, false>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 10, false, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 12, false, false>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 10, false, false>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, true, 12, false, false>));
+        // models with z/r tails or long h lists (m.ext): always on the 10-slot layout, which has registers to spare for them
+        DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, false, true>));  DSS_SET_ATTR((lpcnet_sample_kernel<false, false, 10, true, true>));
+        DSS_SET_ATTR((lpcnet_sample_kernel<true, false, 10, false, true>));
 #undef DSS_SET_ATTR
         attr_set |= 1ull << (dev & 63);
     }
     }
     const bool ragged = b.slot_of || b.count_of;
     if (ragged && trace == 2) { dss_set_error("phase stamps are taken on uniform calls only"); return DSS_EINVAL; }
+    if (m.ext && trace == 2) { dss_set_error("phase stamps are not built for models with z/r tails"); return DSS_EINVAL; }
 #define DSS_LAUNCH(T, S2, R)                                                                                           \
     do {                                                                                                               \
-        if (z10) hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 10, R>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm); \
-        else hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 12, R>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);     \
+        if (z10) hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 10, R, false>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm); \
+        else hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 12, R, false>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);     \
     } while (0)
-    if (trace == 2) DSS_LAUNCH(false, true, false);        // diagnostic: phase stamps (never used for timing claims)
+#define DSS_LAUNCH_EXT(T, R) hipLaunchKernelGGL((lpcnet_sample_kernel<T, false, 10, R, true>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm)
+    if (m.ext) {
+        if (trace) DSS_LAUNCH_EXT(true, false);
+        else if (ragged) DSS_LAUNCH_EXT(false, true);
+        else DSS_LAUNCH_EXT(false, false);
+    }
+    else if (trace == 2) DSS_LAUNCH(false, true, false);   // diagnostic: phase stamps (never used for timing claims)
     else if (trace) DSS_LAUNCH(true, false, false);
     else if (ragged) DSS_LAUNCH(false, false, true);
     else DSS_LAUNCH(false, false, false);
 #undef DSS_LAUNCH
+#undef DSS_LAUNCH_EXT
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }

@@ -20,6 +20,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DSS_H_STORE
 #define DSS_H_STORE(V) L.ah[uh] = (V)
 #endif
+// slots beyond DSS_HC of a long h list (models with skewed sparsity; only the latency kernel defines it)
+#ifndef DSS_H_TAIL
+#define DSS_H_TAIL
+#endif
 
 // one 8x4 block applied to one row: four products accumulated one at a time (sparse_sgemv_accum8x4 order)
 // z/r chunk C = slots 2C, 2C+1 of the z list and of the r list (Q[0..1] z, Q[2..3] r)
@@ -94,6 +98,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
             DSS_H_MAC(HB)                                                                        \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
+        DSS_H_TAIL                                                                               \
         DSS_H_STORE(ah);                                                                         \
     }
 // N inputs (multiple of 16) of the GRU B chain of one row.  Weights come from this lane's registers, the new

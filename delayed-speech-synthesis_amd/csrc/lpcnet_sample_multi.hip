@@ -50,6 +50,7 @@ struct MuShared {                         // static LDS, shared by the utterance
 
 struct MuUtt {                            // dynamic LDS, one per utterance, behind the h-gate block image
     float state_a[NA];                    // GRU A state (single buffer: the rendezvous separates its readers from its writers)
+    float zero4[4];                       // "column 96": the input of the h-gate slots a row group does not use
     float ah[NA];                         // h-gate pre-activation of the coming sample
     float spec_tab_pred[256];             // speculation tables over the 256 possible excitations of the current sample
     unsigned short spec_tab_idx[256];
@@ -189,8 +190,7 @@ __device__ __forceinline__ void mu_role_a(MuShared &S, MuUtt *UT, float *hblk_ld
     const int uh = m.unit_h[tid];                                // h-gate chain of this (other) unit
     const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
     const int nzr = __builtin_amdgcn_readfirstlane(m.wave_nzr[wave]);
-    const char *hw = reinterpret_cast<const char *>(hblk_lds + __builtin_amdgcn_readfirstlane(m.wave_hoff[wave])) +
-                     ((lane >> 3) * (nh + 1) * 128 + (lane & 7) * 16);
+    const char *hw = reinterpret_cast<const char *>(hblk_lds + m.grp_hoff[tid >> 3]) + (lane & 7) * 16;
     f32x4 WZ[2 * ZRC];                                           // [0,ZRC) z slots, [ZRC,2ZRC) r slots
     unsigned PZ[(2 * ZRL + 3) / 4], PH[HC / 4];
 #pragma unroll
@@ -391,6 +391,7 @@ lpcnet_sample_multi_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__
     if (tid == 0) { S.cnt_bits = 0; S.cnt_reads = 0; }
     for (int j = 0; j < U; ++j) {
         const int u = blockIdx.x * U + j;
+        if (tid < 4) UT[j].zero4[tid] = 0.f;
         if (u < n_utts) {
             if (tid < NA) UT[j].state_a[tid] = b.gru_a_state[(size_t)u * NA + tid];
             if (tid < NB) UT[j].state_b[tid] = b.gru_b_state[(size_t)u * NB + tid];
@@ -614,7 +615,7 @@ size_t dss_multi_lds_bytes(const DssModelDev &m, int U)
 // Largest U in {4, 3} whose LDS image fits beside the model's h-gate blocks (0: none; the caller uses the latency kernel)
 int dss_multi_max_u(const DssModelDev &m)
 {
-    if (!m.fast_ok) return 0;
+    if (!m.fast_ok || m.ext) return 0;                       // z/r tails and long h lists: latency kernel only
     const size_t cap = 160 * 1024 - sizeof(MuShared);
     for (int U = MU_MAX; U >= 3; --U)
         if (dss_multi_lds_bytes(m, U) <= cap) return U;
@@ -626,7 +627,7 @@ int dss_launch_sample_network_multi(const DssModelDev &m, DssBatchDev &b, int n_
 {
     if (U < 3 || U > MU_MAX || U > dss_multi_max_u(m)) { dss_set_error("multi-utterance kernel: U = %d not available for this model", U); return DSS_EINVAL; }
     const size_t dyn = dss_multi_lds_bytes(m, U);
-    const bool z10 = m.nzr_max <= 10;
+    const bool z10 = m.zr_cap <= 10;
     static std::mutex attr_mu;
     static unsigned long long attr_set = 0;
     int dev = 0;

@@ -72,6 +72,7 @@ def model_info() -> dict:
     keys = ("fast_path", "zr_slots_max", "h_slots_max", "h_lds_bytes", "gru_a_order")
     info = {k: int(x.value) for k, x in zip(keys, v)}
     info["kernel"] = "lpcnet_sample_kernel" if info["fast_path"] else "lpcnet_sample_generic_kernel"
+    info["extended"] = info["fast_path"] == 2      # z/r tail blocks or long h lists in LDS (skewed sparsity)
     return info
 
 
@@ -96,8 +97,8 @@ class LPCNetBatch:
         info = model_info()
         if not info["fast_path"]:
             import warnings
-            warnings.warn("LPCNet model exceeds the CU-resident kernel's capacities (z/r blocks per row group %d of 12, "
-                          "h blocks %d of 28, LDS image %d of 137728 B): running on the generic kernel, several times slower"
+            warnings.warn("LPCNet model exceeds the CU-resident kernel's capacities (z/r blocks per row group %d of 12+16, "
+                          "h blocks %d of 64, LDS image %d of 138752 B): running on the generic kernel, several times slower"
                           % (info["zr_slots_max"], info["h_slots_max"], info["h_lds_bytes"]), RuntimeWarning, stacklevel=2)
 
     def _check_device(self, t):

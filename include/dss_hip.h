@@ -89,11 +89,15 @@ int dss_lpcnet_load_model_file(const char *path);
 /* SURVEY.md 8(d) algorithmic bytes per output sample for the loaded model (0 if none). */
 double dss_lpcnet_bytes_per_sample(void);
 /* Which sample-rate kernel the loaded model runs on, and why (any pointer may be NULL):
- *   fast_path     1 = CU-resident kernel (all weights in VGPRs/LDS), 0 = generic kernel (GRU A blocks streamed from
- *                 L2, several times slower) because the model exceeds a capacity below;
- *   zr_slots_max  largest z- or r-gate block count of a row group (capacity 12; at most 16 groups above 8);
- *   h_slots_max   largest h-gate block count of a row group (capacity 28);
- *   h_lds_bytes   LDS image of the h-gate blocks (capacity 137 728 B);
+ *   fast_path     1 = CU-resident kernel, all weights in VGPRs/LDS; 2 = the same kernel with its extended paths (a model
+ *                 with skewed sparsity: some row groups keep z/r blocks beyond their wave's register slots as LDS
+ *                 records, or h lists longer than 28 -- a few per cent to tens of per cent slower, same results);
+ *                 0 = generic kernel (GRU A blocks streamed from L2, several times slower) because the model exceeds
+ *                 an outer capacity below;
+ *   zr_slots_max  largest z- or r-gate block count of a row group (register slots: 12 on 16 groups, 8 on the other
+ *                 32; outer capacity: 16 more per group);
+ *   h_slots_max   largest h-gate block count of a row group (28 with register-held column ids; outer capacity 64);
+ *   h_lds_bytes   LDS image: h-gate blocks, z/r tail blocks and their tables (capacity 138 752 B);
  *   gru_a_order   dss_blob_header.gru_a_order of the model. */
 int dss_lpcnet_model_info(int *fast_path, int *zr_slots_max, int *h_slots_max, int *h_lds_bytes, int *gru_a_order);
 

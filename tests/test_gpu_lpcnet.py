@@ -343,27 +343,67 @@ def test_gru_a_recurrent_first_order_flag(oracle):
 
 
 def test_skewed_sparsity_selects_a_kernel_loudly(oracle):
-    """magnitude pruning gives skewed per-row-group block counts.  Whatever kernel such a model lands on,
-    the choice is visible (model_info, a RuntimeWarning for the generic kernel) and the output is bit-exact."""
+    """magnitude pruning gives skewed per-row-group block counts.  Moderately skewed models stay on the
+    CU-resident kernel through its extended paths (z/r blocks beyond the register slots and h slots beyond 28 come from
+    LDS records: model_info fast_path 2); only a model beyond the outer capacities falls to the generic kernel, with a
+    RuntimeWarning.  Whatever the kernel, the choice is visible and the output is bit-exact."""
     import warnings
     from dss_amd import lpcnet
     from dss_amd.lpcnet import LPCNetBatch
-    feats = np.stack([synthetic_features(820 + b, 5) for b in range(2)])
+    feats = np.stack([synthetic_features(820 + b, 6) for b in range(3)])
     try:
-        seen = set()
-        for skew in (0.05, 0.3):          # per-group maxima 16 / 34 and 49 / 51 z-r / h blocks against capacities 12 / 28
-            blob = synthetic_blob(7, skew=skew)
+        seen = {}
+        # per-group maxima (z-r / h blocks): 12/29, 16/34, 26/35, 49/51 against 12 (8) / 28 register-held slots
+        for seed, skew in ((0, 0.02), (7, 0.05), (0, 0.1), (7, 0.3)):
+            blob = synthetic_blob(seed, skew=skew)
             lpcnet.load_model(blob)
             info = lpcnet.model_info()
             with warnings.catch_warnings(record=True) as w:
                 warnings.simplefilter("always")
-                gpu = LPCNetBatch(2, 5)
+                gpu = LPCNetBatch(3, 6)
             assert bool(w) == (not info["fast_path"])
             if w:
                 assert "generic kernel" in str(w[0].message)
-            assert np.array_equal(gpu.synthesize(feats), _oracle_pcm(oracle, blob, feats)), (skew, info)
-            seen.add(info["kernel"])
-        assert "lpcnet_sample_generic_kernel" in seen       # both exceed the CU-resident capacities
+            want = _oracle_pcm(oracle, blob, feats)
+            assert np.array_equal(gpu.synthesize(feats), want), (skew, info)
+            # state carried across calls: 4 + 2 frames equal 6 in one call
+            gpu.reset()
+            got = np.concatenate([gpu.synthesize(feats[:, :4]), gpu.synthesize(feats[:, 4:])], axis=1)
+            assert np.array_equal(got, want), (skew, info)
+            seen[skew] = info["fast_path"]
+        assert seen == {0.02: 2, 0.05: 2, 0.1: 2, 0.3: 0}, seen
+    finally:
+        lpcnet.load_model(synthetic_blob(0))
+
+
+def test_extended_paths_ragged_and_teacher_forced(oracle):
+    """The tail / long-list paths in the other instantiations of the CU-resident kernel: a ragged call (rows with their
+    own frame counts and decoder slots) and the teacher-forced trace build, on a skewed model."""
+    from dss_amd import lpcnet
+    from dss_amd.lpcnet import LPCNetBatch
+    blob = synthetic_blob(0, skew=0.1)
+    try:
+        lpcnet.load_model(blob)
+        assert lpcnet.model_info()["fast_path"] == 2
+        counts = [6, 3, 5]
+        feats = np.stack([synthetic_features(840 + b, 6) for b in range(3)])
+        gpu = LPCNetBatch(3, 6)
+        got = gpu.synthesize_ragged([feats[b, :counts[b]] for b in range(3)])
+        want = _oracle_pcm(oracle, blob, feats)
+        for b in range(3):
+            assert np.array_equal(got[b], want[b, :counts[b] * 160]), b
+        # teacher forcing: every logit of every tree node under a forced excitation
+        exc = np.random.default_rng(5).integers(0, 256, (1, 5 * 160), dtype=np.uint8)
+        g1 = LPCNetBatch(1, 5)
+        g1.enable_trace(1)
+        g1.force_excitation(exc, 5)
+        g1.synthesize(feats[:1, :5])
+        logits = g1.tap(0, 5, 5).reshape(-1, 256)[320:]
+        dec = oracle.decoder(oracle.lpcnet_model(blob))
+        dec.force(exc[0, 320:])
+        for t in range(5):
+            dec.synthesize(feats[0, t])
+        assert np.array_equal(logits, dec.forced_logits)
     finally:
         lpcnet.load_model(synthetic_blob(0))
 
