@@ -336,7 +336,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
             zmax = std::max(zmax, std::max(cnt[g], cnt[G + g]));
             hmax = std::max(hmax, cnt[2 * G + g]);
         }
-        if (hmax > DSS_HC + DSS_HX) fast_ok = 0;
+        if (hmax > DSS_HCX + DSS_HX) fast_ok = 0;
         // Two independent lane assignments, both "8 row groups per wave":
         //  * h-gate chains (LDS resident): groups sorted by h block count, so each wave's loop length (its
         //    largest group) is close to what all its groups need;
@@ -399,7 +399,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         // group of the z/r assignment (same over-read convention), then a table
         //   int   tail_off[48][2]                float offset of the group's z list and of its r list
         //   uint8 tail_col[48][2][DSS_ZR_TAIL]   block column of every tail slot (96 = unused)
-        //   uint8 hx_col[48][DSS_HX]             block column of h slots DSS_HC.. of the group of the h assignment
+        //   uint8 hx_col[48][DSS_HX]             block column of h slots DSS_HCX.. of the group of the h assignment
         const int ext_tab_floats = (G * 2 * 4 + G * 2 * DSS_ZR_TAIL + G * DSS_HX) / 4;
         std::vector<int> tail_off(G * 2, 0);
         int ext_tab = 0;
@@ -419,7 +419,7 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         }
         if ((size_t)hfloats * sizeof(float) > DSS_HBLK_BYTES) fast_ok = 0;
         std::vector<float> zr_w((size_t)2 * DSS_ZRC * 4 * NA, 0.f), hblk((size_t)std::max(hfloats, 4), 0.f);
-        std::vector<unsigned> zr_col((size_t)(2 * DSS_ZRC / 4) * NA, 0u), h_col((size_t)(DSS_HC / 4) * NA, 0u);
+        std::vector<unsigned> zr_col((size_t)(2 * DSS_ZRC / 4) * NA, 0u), h_col((size_t)(DSS_HCX / 4) * NA, 0u);
         if (fast_ok)
             for (int tid = 0; tid < NA; ++tid) {
                 const int wv = tid / 64, l = tid & 63, q = l / 8, r = l & 7;
@@ -449,9 +449,9 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
                         const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
                         float *rec = hblk.data() + grp_hoff[wv * 8 + q] + (size_t)sl * 32 + r * 4;
                         for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
-                        if (sl < DSS_HC) h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
+                        if (sl < DSS_HCX) h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
                     }
-                    for (int sl = cnt[g]; sl < DSS_HC; ++sl) h_col[(size_t)(sl >> 2) * NA + tid] |= 96u << (8 * (sl & 3));
+                    for (int sl = cnt[g]; sl < DSS_HCX; ++sl) h_col[(size_t)(sl >> 2) * NA + tid] |= 96u << (8 * (sl & 3));
                 }
             }
         if (fast_ok && ext) {
@@ -469,8 +469,8 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
                             tcol[((size_t)(wv * 8 + q) * 2 + gate) * DSS_ZR_TAIL + (sl - cap)] = (unsigned char)(v.gru_a_idx[start[g] + sl] / 4);
                     }
                     const int gh = 2 * G + grp_h[wv * 8 + q];
-                    for (int sl = DSS_HC; sl < cnt[gh]; ++sl)
-                        hxc[(size_t)(wv * 8 + q) * DSS_HX + (sl - DSS_HC)] = (unsigned char)(v.gru_a_idx[start[gh] + sl] / 4);
+                    for (int sl = DSS_HCX; sl < cnt[gh]; ++sl)
+                        hxc[(size_t)(wv * 8 + q) * DSS_HX + (sl - DSS_HCX)] = (unsigned char)(v.gru_a_idx[start[gh] + sl] / 4);
                 }
         }
         m.fast_ok = fast_ok;

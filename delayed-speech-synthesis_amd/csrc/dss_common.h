@@ -22,13 +22,14 @@
 #define DSS_FEATURES_DELAY 2
 // Capacities of the CU-resident sample-rate kernel (lpcnet_sample.hip).  Row groups with more z/r blocks than their
 // wave has register slots keep the surplus ("tail", in idx order behind the register slots) as LDS records next to the
-// h-gate image, and h lists longer than DSS_HC take the column ids of the further slots from LDS: slower per extra block,
-// same results.  A model that exceeds the outer limits (DSS_ZR_TAIL, DSS_HX, or whose LDS image does not fit
+// h-gate image, and h lists longer than DSS_HCX take the column ids of the further slots from LDS: slower per extra
+// block, same results.  A model that exceeds the outer limits (DSS_ZR_TAIL, DSS_HX, or whose LDS image does not fit
 // DSS_HBLK_BYTES) runs on the generic kernel instead.
 #define DSS_ZRC 12            // register slots per lane for the z-gate and for the r-gate 8x4 blocks
 #define DSS_HC 28             // h-gate slots per row group whose column ids sit in VGPRs (7)
 #define DSS_ZR_TAIL 16        // max z (and r) blocks per row group beyond its wave's register slots
-#define DSS_HX 36             // max h-gate blocks per row group beyond DSS_HC
+#define DSS_HCX 32            // ... in the instantiation with the extended paths (8 VGPRs)
+#define DSS_HX 32             // max h-gate blocks per row group beyond DSS_HCX (column ids from LDS)
 #define DSS_HBLK_BYTES 138752  // dynamic LDS left after the kernel's static 24.5 KB (160 KB per CU)
 
 void dss_set_error(const char *fmt, ...);
@@ -90,7 +91,7 @@ struct DssModelDev {
     const int *wave_nzt;          // [8]   per wave: z/r tail slots (LDS records), max over its groups and both gates
     const float *zr_w;            // [2*DSS_ZRC][4][384] z then r block weights per lane slot, zero padded
     const unsigned *zr_col;       // [2*DSS_ZRC/4][384]  four 8-bit block column ids (pos/4) per word
-    const unsigned *h_col;        // [DSS_HC/4][384]     same for the h-gate slots of the lane's row group
+    const unsigned *h_col;        // [DSS_HCX/4][384]    same for the h-gate slots of the lane's row group
     const float *hblk;            // LDS image: one list of [8 rows][4] records per row group, lists back to back (see dss_capi.cpp)
     const float *gb_w_lane;       // [384][64] GRU B input weights, input-major, lane = row (rows 48..63 zero)
 };

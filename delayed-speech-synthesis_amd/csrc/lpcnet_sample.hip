@@ -27,7 +27,7 @@
 // and the library is built with -ffp-contract=off, so results are bit-identical to the scalar C path.
 #include <mutex>
 
-// h-gate slots DSS_HC.. of a long list: column ids from the table behind the LDS image instead of registers, one chunk of
+// h-gate slots DSS_HCX.. of a long list: column ids from the table behind the LDS image instead of registers, one chunk of
 // two blocks per trip (a dependent LDS round trip for the ids: slower per block than the register-id loop, same sums)
 #define DSS_H_TAIL                                                                               \
     if constexpr (EXT) if (nh > HC) {                                                            \
@@ -44,6 +44,7 @@
         }                                                                                        \
     }
 #include "lpcnet_sample_common.h"
+#undef HC                                  // a constant of the role here: DSS_HC, or DSS_HCX with the extended paths
 
 #define GBH6 208                          // GRU B inputs whose weights sit in wave 6's VGPRs (0..207)
 #define GBH7 112                          // ... in wave 7's VGPRs (208..319); wave 7 also carries the scalar state
@@ -167,6 +168,7 @@ template <bool TRACE, bool STAMP, int Z, bool HAS_FC, bool EXT>
 __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const DssModelDev &m, const DssBatchDev &b,
                                            int n_frames, int utt, int slot, int nf, int fc0, int tid, int wave, int lane)
 {
+    constexpr int HC = EXT ? DSS_HCX : DSS_HC;                   // h slots with register-held column ids
     const int unit = m.unit_of[tid];                             // z/r chains + gates of this unit
     const int uh = m.unit_h[tid];                                // h-gate chain of this (other) unit
     const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
