@@ -256,6 +256,173 @@ extern "C" double dss_lpcnet_bytes_per_sample(void)
     return g_model ? g_model->bytes_per_sample : 0.0;
 }
 
+// ---- CU-resident layout of the sample-rate kernel (lpcnet_sample.hip): pure host work, no device calls -----------
+struct FastLayout {
+    int fast_ok = 0, zmax = 0, hmax = 0, zr_cap = 10, ext = 0, ext_tab = 0, hfloats = 0;
+    std::vector<int> unit_of, unit_h, wave_nh, grp_hoff, wave_nzr, wave_nzt;
+    std::vector<float> zr_w, hblk;
+    std::vector<unsigned> zr_col, h_col;
+};
+
+static void build_fast_layout(const BlobView &v, int NA, FastLayout &F)
+{
+    const int G = NA / 8;                       // 48 row groups per gate
+    std::vector<int> cnt(3 * G), start(3 * G), blk0(3 * G);
+    long pos = 0, blk = 0;
+    for (int g = 0; g < 3 * G; ++g) {
+        cnt[g] = v.gru_a_idx[pos]; start[g] = (int)pos + 1; blk0[g] = (int)blk;
+        pos += 1 + cnt[g]; blk += cnt[g];
+    }
+    int fast_ok = (NA == 384 && G == 48);
+    int zmax = 0, hmax = 0;
+    for (int g = 0; g < G; ++g) {
+        zmax = std::max(zmax, std::max(cnt[g], cnt[G + g]));
+        hmax = std::max(hmax, cnt[2 * G + g]);
+    }
+    if (hmax > DSS_HCX + DSS_HX) fast_ok = 0;
+    // Two independent lane assignments, both "8 row groups per wave":
+    //  * h-gate chains (LDS resident): groups sorted by h block count, so each wave's loop length (its
+    //    largest group) is close to what all its groups need;
+    //  * z/r chains (register resident): groups sorted by max(z, r) block count.  The 16 heaviest groups go to
+    //    waves 4 and 5, whose code path carries no dual-FC weights and therefore has room for zr_cap register
+    //    slots per gate; waves 0..3 run the 8-slot instantiation.  Blocks beyond a wave's register slots (models
+    //    with skewed sparsity) stay in idx order behind them as "tail" records in LDS.
+    // Both the h chain and the z/r block products run between barriers B and C, under the GRU B relay; waves 4
+    // and 5 also run the speculation there, so they get the lightest h chains, and among waves 0..3 the heavier
+    // z/r groups go with the lighter h chains.
+    // The per-unit pre-activation of the h gate travels from its h lane to its z/r lane through LDS.
+    std::vector<int> order_h(G), order_zr(G);
+    for (int g = 0; g < G; ++g) order_h[g] = order_zr[g] = g;
+    std::stable_sort(order_h.begin(), order_h.end(), [&](int a, int b2) { return cnt[2 * G + a] > cnt[2 * G + b2]; });
+    std::stable_sort(order_zr.begin(), order_zr.end(), [&](int a, int b2) {
+        return std::max(cnt[a], cnt[G + a]) > std::max(cnt[b2], cnt[G + b2]);
+    });
+    // Register slots per gate on waves 4, 5.  A model that fits the register slots as it is runs the 10-slot
+    // instantiation (no spills) or, with 11 or 12 blocks in some group, the 12-slot one (22 spilled registers, ~4 %
+    // slower).  Any other model runs the 10-slot layout with tails: measured faster than 12 slots + tails
+    // (tools/model_fit.py), the spills cost more than the two extra tail blocks.
+    const int zr17 = std::max(cnt[order_zr[16]], cnt[G + order_zr[16]]);      // heaviest group that lands on waves 0..3
+    const bool plain = zmax <= DSS_ZRC && zr17 <= 8 && hmax <= DSS_HC;
+    const int zr_cap = (plain && zmax > 10) ? DSS_ZRC : 10;
+    static const int rank_wave_h[6] = {0, 1, 3, 2, 5, 4};
+    static const int rank_wave_zr[6] = {4, 5, 2, 3, 1, 0};
+    std::vector<int> grp_h(G, 0), grp_zr(G, 0);
+    std::vector<int> &unit_of = F.unit_of, &unit_h = F.unit_h, &wave_nh = F.wave_nh, &grp_hoff = F.grp_hoff, &wave_nzr = F.wave_nzr, &wave_nzt = F.wave_nzt;
+    unit_of.assign(NA, 0); unit_h.assign(NA, 0); wave_nh.assign(8, 0); grp_hoff.assign(G, 0); wave_nzr.assign(8, 0); wave_nzt.assign(8, 0);
+    int hfloats = 0, ext = 0;
+    for (int rk = 0; rk < 6 && fast_ok; ++rk) {
+        int nh = 0, nzr = 0;
+        for (int q = 0; q < 8; ++q) {
+            grp_h[rank_wave_h[rk] * 8 + q] = order_h[rk * 8 + q];
+            grp_zr[rank_wave_zr[rk] * 8 + q] = order_zr[rk * 8 + q];
+            nh = std::max(nh, cnt[2 * G + order_h[rk * 8 + q]]);
+            nzr = std::max(nzr, std::max(cnt[order_zr[rk * 8 + q]], cnt[G + order_zr[rk * 8 + q]]));
+        }
+        const int cap = rank_wave_zr[rk] < 4 ? 8 : zr_cap;
+        wave_nh[rank_wave_h[rk]] = (nh + 1) & ~1;       // the kernel tests for the end of a list every 2 slots
+        wave_nzr[rank_wave_zr[rk]] = std::min((nzr + 1) & ~1, cap);
+        wave_nzt[rank_wave_zr[rk]] = std::max(0, nzr - cap);
+        if (nzr - cap > DSS_ZR_TAIL) fast_ok = 0;
+        if (nzr > cap || nh > DSS_HC) ext = 1;
+    }
+    // The h-gate image: every row group's own records back to back (128 bytes = [8 rows][4 inputs] per block), no
+    // padding to the wave's longest list.  A wave still runs wave_nh slots on all its lanes: a lane whose group is
+    // shorter reads on into the next group's records and multiplies them by "column 96", four zeros behind the
+    // state vector, so the extra terms are +-0.  One spare record goes between two groups of a wave whenever
+    // they would otherwise start an even number of records apart: 8-lane groups that start 32 banks apart keep
+    // the wave's ds_read_b128 of its block records conflict-free.
+    int hend = 0;
+    for (int wv = 0; wv < 6 && fast_ok; ++wv)
+        for (int q = 0; q < 8; ++q) {
+            if (q && (((hfloats - grp_hoff[wv * 8 + q - 1]) / 32) & 1) == 0) hfloats += 32;
+            grp_hoff[wv * 8 + q] = hfloats;
+            hfloats += cnt[2 * G + grp_h[wv * 8 + q]] * 32;
+            hend = std::max(hend, grp_hoff[wv * 8 + q] + wave_nh[wv] * 32);
+        }
+    hfloats = std::max(hfloats, hend);                  // the last groups' over-reads stay inside the image
+    // Extended paths (models with skewed sparsity only): behind the h records, the z and r tail lists of every
+    // group of the z/r assignment (same over-read convention), then a table
+    //   int   tail_off[48][2]                float offset of the group's z list and of its r list
+    //   uint8 tail_col[48][2][DSS_ZR_TAIL]   block column of every tail slot (96 = unused)
+    //   uint8 hx_col[48][DSS_HX]             block column of h slots DSS_HCX.. of the group of the h assignment
+    const int ext_tab_floats = (G * 2 * 4 + G * 2 * DSS_ZR_TAIL + G * DSS_HX) / 4;
+    std::vector<int> tail_off(G * 2, 0);
+    int ext_tab = 0;
+    if (fast_ok && ext) {
+        int tend = hfloats;
+        for (int wv = 0; wv < 6; ++wv)
+            for (int q = 0; q < 8; ++q)
+                for (int gate = 0; gate < 2; ++gate) {
+                    const int cap = wv < 4 ? 8 : zr_cap, n = cnt[gate * G + grp_zr[wv * 8 + q]];
+                    tail_off[(wv * 8 + q) * 2 + gate] = hfloats;
+                    tend = std::max(tend, hfloats + wave_nzt[wv] * 32);
+                    hfloats += std::max(0, n - cap) * 32;
+                }
+        hfloats = std::max(hfloats, tend);
+        ext_tab = hfloats;
+        hfloats += ext_tab_floats;
+    }
+    if ((size_t)hfloats * sizeof(float) > DSS_HBLK_BYTES) fast_ok = 0;
+    std::vector<float> &zr_w = F.zr_w, &hblk = F.hblk;
+    std::vector<unsigned> &zr_col = F.zr_col, &h_col = F.h_col;
+    zr_w.assign((size_t)2 * DSS_ZRC * 4 * NA, 0.f); hblk.assign((size_t)std::max(hfloats, 4), 0.f);
+    zr_col.assign((size_t)(2 * DSS_ZRC / 4) * NA, 0u); h_col.assign((size_t)(DSS_HCX / 4) * NA, 0u);
+    if (fast_ok)
+        for (int tid = 0; tid < NA; ++tid) {
+            const int wv = tid / 64, l = tid & 63, q = l / 8, r = l & 7;
+            {
+                const int grp = grp_zr[wv * 8 + q];
+                unit_of[tid] = grp * 8 + r;
+                const int cap = wv < 4 ? 8 : zr_cap;
+                for (int gate = 0; gate < 2; ++gate) {
+                    const int g = gate * G + grp;
+                    for (int sl = 0; sl < std::min(cnt[g], cap); ++sl) {
+                        const int s2 = gate * DSS_ZRC + sl;
+                        const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                        for (int k = 0; k < 4; ++k) zr_w[((size_t)s2 * 4 + k) * NA + tid] = wb[k * 8 + r];
+                        zr_col[(size_t)(s2 >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (s2 & 3));
+                    }
+                    for (int sl = cap; sl < cnt[g]; ++sl) {              // tail: LDS records, columns in the table
+                        const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                        float *rec = hblk.data() + tail_off[(wv * 8 + q) * 2 + gate] + (size_t)(sl - cap) * 32 + r * 4;
+                        for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
+                    }
+                }
+            }
+            {
+                const int grp = grp_h[wv * 8 + q], g = 2 * G + grp;
+                unit_h[tid] = grp * 8 + r;
+                for (int sl = 0; sl < cnt[g]; ++sl) {
+                    const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                    float *rec = hblk.data() + grp_hoff[wv * 8 + q] + (size_t)sl * 32 + r * 4;
+                    for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
+                    if (sl < DSS_HCX) h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
+                }
+                for (int sl = cnt[g]; sl < DSS_HCX; ++sl) h_col[(size_t)(sl >> 2) * NA + tid] |= 96u << (8 * (sl & 3));
+            }
+        }
+    if (fast_ok && ext) {
+        int *toff = reinterpret_cast<int *>(hblk.data() + ext_tab);
+        unsigned char *tcol = reinterpret_cast<unsigned char *>(toff + G * 2);
+        unsigned char *hxc = tcol + (size_t)G * 2 * DSS_ZR_TAIL;
+        memset(tcol, 96, (size_t)G * 2 * DSS_ZR_TAIL + (size_t)G * DSS_HX);
+        for (int wv = 0; wv < 6; ++wv)
+            for (int q = 0; q < 8; ++q) {
+                const int cap = wv < 4 ? 8 : zr_cap;
+                for (int gate = 0; gate < 2; ++gate) {
+                    const int g = gate * G + grp_zr[wv * 8 + q];
+                    toff[(wv * 8 + q) * 2 + gate] = tail_off[(wv * 8 + q) * 2 + gate];
+                    for (int sl = cap; sl < cnt[g]; ++sl)
+                        tcol[((size_t)(wv * 8 + q) * 2 + gate) * DSS_ZR_TAIL + (sl - cap)] = (unsigned char)(v.gru_a_idx[start[g] + sl] / 4);
+                }
+                const int gh = 2 * G + grp_h[wv * 8 + q];
+                for (int sl = DSS_HCX; sl < cnt[gh]; ++sl)
+                    hxc[(size_t)(wv * 8 + q) * DSS_HX + (sl - DSS_HCX)] = (unsigned char)(v.gru_a_idx[start[gh] + sl] / 4);
+            }
+    }
+    F.fast_ok = fast_ok; F.zmax = zmax; F.hmax = hmax; F.zr_cap = zr_cap; F.ext = fast_ok ? ext : 0; F.ext_tab = ext_tab; F.hfloats = hfloats;
+}
+
 static int upload_model(HostModel *hm, int device, DssModelDev &m)
 {
     BlobView v;
@@ -323,156 +490,12 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
     }
     // ---- CU-resident layout of the sample-rate kernel (lpcnet_sample.hip) ---------------------------------
     {
-        const int G = NA / 8;                       // 48 row groups per gate
-        std::vector<int> cnt(3 * G), start(3 * G), blk0(3 * G);
-        long pos = 0, blk = 0;
-        for (int g = 0; g < 3 * G; ++g) {
-            cnt[g] = v.gru_a_idx[pos]; start[g] = (int)pos + 1; blk0[g] = (int)blk;
-            pos += 1 + cnt[g]; blk += cnt[g];
-        }
-        int fast_ok = (NA == 384 && G == 48);
-        int zmax = 0, hmax = 0;
-        for (int g = 0; g < G; ++g) {
-            zmax = std::max(zmax, std::max(cnt[g], cnt[G + g]));
-            hmax = std::max(hmax, cnt[2 * G + g]);
-        }
-        if (hmax > DSS_HCX + DSS_HX) fast_ok = 0;
-        // Two independent lane assignments, both "8 row groups per wave":
-        //  * h-gate chains (LDS resident): groups sorted by h block count, so each wave's loop length (its
-        //    largest group) is close to what all its groups need;
-        //  * z/r chains (register resident): groups sorted by max(z, r) block count.  The 16 heaviest groups go to
-        //    waves 4 and 5, whose code path carries no dual-FC weights and therefore has room for zr_cap register
-        //    slots per gate; waves 0..3 run the 8-slot instantiation.  Blocks beyond a wave's register slots (models
-        //    with skewed sparsity) stay in idx order behind them as "tail" records in LDS.
-        // Both the h chain and the z/r block products run between barriers B and C, under the GRU B relay; waves 4
-        // and 5 also run the speculation there, so they get the lightest h chains, and among waves 0..3 the heavier
-        // z/r groups go with the lighter h chains.
-        // The per-unit pre-activation of the h gate travels from its h lane to its z/r lane through LDS.
-        std::vector<int> order_h(G), order_zr(G);
-        for (int g = 0; g < G; ++g) order_h[g] = order_zr[g] = g;
-        std::stable_sort(order_h.begin(), order_h.end(), [&](int a, int b2) { return cnt[2 * G + a] > cnt[2 * G + b2]; });
-        std::stable_sort(order_zr.begin(), order_zr.end(), [&](int a, int b2) {
-            return std::max(cnt[a], cnt[G + a]) > std::max(cnt[b2], cnt[G + b2]);
-        });
-        // Register slots per gate on waves 4, 5.  A model that fits the register slots as it is runs the 10-slot
-        // instantiation (no spills) or, with 11 or 12 blocks in some group, the 12-slot one (22 spilled registers, ~4 %
-        // slower).  Any other model runs the 10-slot layout with tails: measured faster than 12 slots + tails
-        // (tools/model_fit.py), the spills cost more than the two extra tail blocks.
-        const int zr17 = std::max(cnt[order_zr[16]], cnt[G + order_zr[16]]);      // heaviest group that lands on waves 0..3
-        const bool plain = zmax <= DSS_ZRC && zr17 <= 8 && hmax <= DSS_HC;
-        const int zr_cap = (plain && zmax > 10) ? DSS_ZRC : 10;
-        static const int rank_wave_h[6] = {0, 1, 3, 2, 5, 4};
-        static const int rank_wave_zr[6] = {4, 5, 2, 3, 1, 0};
-        std::vector<int> unit_of(NA, 0), unit_h(NA, 0), wave_nh(8, 0), grp_hoff(G, 0), wave_nzr(8, 0), wave_nzt(8, 0), grp_h(G, 0), grp_zr(G, 0);
-        int hfloats = 0, ext = 0;
-        for (int rk = 0; rk < 6 && fast_ok; ++rk) {
-            int nh = 0, nzr = 0;
-            for (int q = 0; q < 8; ++q) {
-                grp_h[rank_wave_h[rk] * 8 + q] = order_h[rk * 8 + q];
-                grp_zr[rank_wave_zr[rk] * 8 + q] = order_zr[rk * 8 + q];
-                nh = std::max(nh, cnt[2 * G + order_h[rk * 8 + q]]);
-                nzr = std::max(nzr, std::max(cnt[order_zr[rk * 8 + q]], cnt[G + order_zr[rk * 8 + q]]));
-            }
-            const int cap = rank_wave_zr[rk] < 4 ? 8 : zr_cap;
-            wave_nh[rank_wave_h[rk]] = (nh + 1) & ~1;       // the kernel tests for the end of a list every 2 slots
-            wave_nzr[rank_wave_zr[rk]] = std::min((nzr + 1) & ~1, cap);
-            wave_nzt[rank_wave_zr[rk]] = std::max(0, nzr - cap);
-            if (nzr - cap > DSS_ZR_TAIL) fast_ok = 0;
-            if (nzr > cap || nh > DSS_HC) ext = 1;
-        }
-        // The h-gate image: every row group's own records back to back (128 bytes = [8 rows][4 inputs] per block), no
-        // padding to the wave's longest list.  A wave still runs wave_nh slots on all its lanes: a lane whose group is
-        // shorter reads on into the next group's records and multiplies them by "column 96", four zeros behind the
-        // state vector, so the extra terms are +-0.  One spare record goes between two groups of a wave whenever
-        // they would otherwise start an even number of records apart: 8-lane groups that start 32 banks apart keep
-        // the wave's ds_read_b128 of its block records conflict-free.
-        int hend = 0;
-        for (int wv = 0; wv < 6 && fast_ok; ++wv)
-            for (int q = 0; q < 8; ++q) {
-                if (q && (((hfloats - grp_hoff[wv * 8 + q - 1]) / 32) & 1) == 0) hfloats += 32;
-                grp_hoff[wv * 8 + q] = hfloats;
-                hfloats += cnt[2 * G + grp_h[wv * 8 + q]] * 32;
-                hend = std::max(hend, grp_hoff[wv * 8 + q] + wave_nh[wv] * 32);
-            }
-        hfloats = std::max(hfloats, hend);                  // the last groups' over-reads stay inside the image
-        // Extended paths (models with skewed sparsity only): behind the h records, the z and r tail lists of every
-        // group of the z/r assignment (same over-read convention), then a table
-        //   int   tail_off[48][2]                float offset of the group's z list and of its r list
-        //   uint8 tail_col[48][2][DSS_ZR_TAIL]   block column of every tail slot (96 = unused)
-        //   uint8 hx_col[48][DSS_HX]             block column of h slots DSS_HCX.. of the group of the h assignment
-        const int ext_tab_floats = (G * 2 * 4 + G * 2 * DSS_ZR_TAIL + G * DSS_HX) / 4;
-        std::vector<int> tail_off(G * 2, 0);
-        int ext_tab = 0;
-        if (fast_ok && ext) {
-            int tend = hfloats;
-            for (int wv = 0; wv < 6; ++wv)
-                for (int q = 0; q < 8; ++q)
-                    for (int gate = 0; gate < 2; ++gate) {
-                        const int cap = wv < 4 ? 8 : zr_cap, n = cnt[gate * G + grp_zr[wv * 8 + q]];
-                        tail_off[(wv * 8 + q) * 2 + gate] = hfloats;
-                        tend = std::max(tend, hfloats + wave_nzt[wv] * 32);
-                        hfloats += std::max(0, n - cap) * 32;
-                    }
-            hfloats = std::max(hfloats, tend);
-            ext_tab = hfloats;
-            hfloats += ext_tab_floats;
-        }
-        if ((size_t)hfloats * sizeof(float) > DSS_HBLK_BYTES) fast_ok = 0;
-        std::vector<float> zr_w((size_t)2 * DSS_ZRC * 4 * NA, 0.f), hblk((size_t)std::max(hfloats, 4), 0.f);
-        std::vector<unsigned> zr_col((size_t)(2 * DSS_ZRC / 4) * NA, 0u), h_col((size_t)(DSS_HCX / 4) * NA, 0u);
-        if (fast_ok)
-            for (int tid = 0; tid < NA; ++tid) {
-                const int wv = tid / 64, l = tid & 63, q = l / 8, r = l & 7;
-                {
-                    const int grp = grp_zr[wv * 8 + q];
-                    unit_of[tid] = grp * 8 + r;
-                    const int cap = wv < 4 ? 8 : zr_cap;
-                    for (int gate = 0; gate < 2; ++gate) {
-                        const int g = gate * G + grp;
-                        for (int sl = 0; sl < std::min(cnt[g], cap); ++sl) {
-                            const int s2 = gate * DSS_ZRC + sl;
-                            const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                            for (int k = 0; k < 4; ++k) zr_w[((size_t)s2 * 4 + k) * NA + tid] = wb[k * 8 + r];
-                            zr_col[(size_t)(s2 >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (s2 & 3));
-                        }
-                        for (int sl = cap; sl < cnt[g]; ++sl) {              // tail: LDS records, columns in the table
-                            const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                            float *rec = hblk.data() + tail_off[(wv * 8 + q) * 2 + gate] + (size_t)(sl - cap) * 32 + r * 4;
-                            for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
-                        }
-                    }
-                }
-                {
-                    const int grp = grp_h[wv * 8 + q], g = 2 * G + grp;
-                    unit_h[tid] = grp * 8 + r;
-                    for (int sl = 0; sl < cnt[g]; ++sl) {
-                        const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                        float *rec = hblk.data() + grp_hoff[wv * 8 + q] + (size_t)sl * 32 + r * 4;
-                        for (int k = 0; k < 4; ++k) rec[k] = wb[k * 8 + r];
-                        if (sl < DSS_HCX) h_col[(size_t)(sl >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
-                    }
-                    for (int sl = cnt[g]; sl < DSS_HCX; ++sl) h_col[(size_t)(sl >> 2) * NA + tid] |= 96u << (8 * (sl & 3));
-                }
-            }
-        if (fast_ok && ext) {
-            int *toff = reinterpret_cast<int *>(hblk.data() + ext_tab);
-            unsigned char *tcol = reinterpret_cast<unsigned char *>(toff + G * 2);
-            unsigned char *hxc = tcol + (size_t)G * 2 * DSS_ZR_TAIL;
-            memset(tcol, 96, (size_t)G * 2 * DSS_ZR_TAIL + (size_t)G * DSS_HX);
-            for (int wv = 0; wv < 6; ++wv)
-                for (int q = 0; q < 8; ++q) {
-                    const int cap = wv < 4 ? 8 : zr_cap;
-                    for (int gate = 0; gate < 2; ++gate) {
-                        const int g = gate * G + grp_zr[wv * 8 + q];
-                        toff[(wv * 8 + q) * 2 + gate] = tail_off[(wv * 8 + q) * 2 + gate];
-                        for (int sl = cap; sl < cnt[g]; ++sl)
-                            tcol[((size_t)(wv * 8 + q) * 2 + gate) * DSS_ZR_TAIL + (sl - cap)] = (unsigned char)(v.gru_a_idx[start[g] + sl] / 4);
-                    }
-                    const int gh = 2 * G + grp_h[wv * 8 + q];
-                    for (int sl = DSS_HCX; sl < cnt[gh]; ++sl)
-                        hxc[(size_t)(wv * 8 + q) * DSS_HX + (sl - DSS_HCX)] = (unsigned char)(v.gru_a_idx[start[gh] + sl] / 4);
-                }
-        }
+        FastLayout F;
+        build_fast_layout(v, NA, F);
+        const std::vector<int> &unit_of = F.unit_of, &unit_h = F.unit_h, &wave_nh = F.wave_nh, &grp_hoff = F.grp_hoff, &wave_nzr = F.wave_nzr, &wave_nzt = F.wave_nzt;
+        const std::vector<float> &zr_w = F.zr_w, &hblk = F.hblk;
+        const std::vector<unsigned> &zr_col = F.zr_col, &h_col = F.h_col;
+        const int fast_ok = F.fast_ok, zmax = F.zmax, hmax = F.hmax, zr_cap = F.zr_cap, ext = F.ext, ext_tab = F.ext_tab, hfloats = F.hfloats;
         m.fast_ok = fast_ok;
         m.nzr_max = (zmax + 1) & ~1;
         m.zr_cap = zr_cap;
@@ -999,6 +1022,107 @@ extern "C" int lpcnet_compute_single_frame_features(LPCNetEncState *, const shor
     return -1;
 }
 // cLPCNet.pxd:22-23 declares decode_packet inside a stray header block; nothing calls it
+
+// Host-only check of build_fast_layout(): walks every lane's z, r and h lists through the arrays exactly as the kernel
+// indexes them (register slots, tail records, long-list columns, over-reads) and compares the blocks it would multiply, in
+// order, with the row's blocks in the blob.  Needs no GPU (tests/test_cpu_layout.py).
+extern "C" int dss_selftest_fast_layout(const void *blob, size_t len, int *info)
+{
+    if (!blob || !info || len < sizeof(dss_blob_header)) { dss_set_error("dss_selftest_fast_layout: bad arguments"); return DSS_EINVAL; }
+    dss_blob_header h;
+    memcpy(&h, blob, sizeof(h));
+    int rc = check_header(h);
+    if (rc) return rc;
+    std::vector<char> copy((const char *)blob, (const char *)blob + len);
+    BlobView v;
+    rc = view_blob(copy, h, v);
+    if (rc) return rc;
+    const int NA = h.gru_a, G = NA / 8;
+    FastLayout F;
+    build_fast_layout(v, NA, F);
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    info[0] = F.fast_ok ? (F.ext ? 2 : 1) : 0;
+    info[1] = F.zmax; info[2] = F.hmax; info[3] = F.hfloats * 4; info[4] = F.zr_cap;
+    if (!F.fast_ok) return DSS_OK;
+    std::vector<int> cnt(3 * G), start(3 * G), blk0(3 * G);
+    long pos = 0, blk = 0;
+    for (int g = 0; g < 3 * G; ++g) { cnt[g] = v.gru_a_idx[pos]; start[g] = (int)pos + 1; blk0[g] = (int)blk; pos += 1 + cnt[g]; blk += cnt[g]; }
+    int mismatches = 0, oob = 0, tails = 0;
+    const int rec_end = F.ext ? F.ext_tab : F.hfloats;                 // records may be read up to here
+    const int *toff = reinterpret_cast<const int *>(F.hblk.data() + F.ext_tab);
+    const unsigned char *tcol = reinterpret_cast<const unsigned char *>(toff + G * 2);
+    const unsigned char *hxc = tcol + (size_t)G * 2 * DSS_ZR_TAIL;
+    std::vector<int> seen_zr(NA, 0), seen_h(NA, 0);
+    struct Blk { int col; float w[4]; };
+    auto compare = [&](const std::vector<Blk> &got, int g, int r) {
+        // drop the terms that are +-0 by construction: zero column, or an all-zero padded register slot
+        std::vector<Blk> eff;
+        for (const Blk &b : got) {
+            if (b.col == 96) continue;
+            if (b.w[0] == 0.f && b.w[1] == 0.f && b.w[2] == 0.f && b.w[3] == 0.f) continue;
+            eff.push_back(b);
+        }
+        if ((int)eff.size() != cnt[g]) { ++mismatches; return; }
+        for (int sl = 0; sl < cnt[g]; ++sl) {
+            const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+            if (eff[sl].col != v.gru_a_idx[start[g] + sl] / 4) { ++mismatches; return; }
+            for (int k = 0; k < 4; ++k) if (eff[sl].w[k] != wb[k * 8 + r]) { ++mismatches; return; }
+        }
+    };
+    for (int tid = 0; tid < NA; ++tid) {
+        const int wave = tid / 64, lane = tid & 63, grp2 = tid >> 3;
+        {   // z and r lists of unit_of[tid]
+            const int unit = F.unit_of[tid];
+            if (unit < 0 || unit >= NA) { ++mismatches; continue; }
+            ++seen_zr[unit];
+            const int zreg = wave < 4 ? 8 : F.zr_cap, nzr = F.wave_nzr[wave], nzt = F.ext ? F.wave_nzt[wave] : 0;
+            if (nzr > zreg || (!F.ext && F.wave_nzt[wave])) ++mismatches;
+            for (int gate = 0; gate < 2; ++gate) {
+                std::vector<Blk> got;
+                for (int sl = 0; sl < nzr; ++sl) {
+                    const int s2 = gate * DSS_ZRC + sl;
+                    Blk b;
+                    b.col = (F.zr_col[(size_t)(s2 >> 2) * NA + tid] >> (8 * (s2 & 3))) & 0xFF;
+                    for (int k = 0; k < 4; ++k) b.w[k] = F.zr_w[((size_t)s2 * 4 + k) * NA + tid];
+                    got.push_back(b);
+                }
+                for (int sl = 0; sl < nzt; ++sl) {
+                    const int off = toff[grp2 * 2 + gate] + sl * 32 + (lane & 7) * 4;
+                    if (off < 0 || off + 4 > rec_end) { ++oob; continue; }
+                    Blk b;
+                    b.col = tcol[((size_t)grp2 * 2 + gate) * DSS_ZR_TAIL + sl];
+                    for (int k = 0; k < 4; ++k) b.w[k] = F.hblk[off + k];
+                    if (b.col != 96) ++tails;
+                    got.push_back(b);
+                }
+                compare(got, gate * G + unit / 8, unit & 7);
+            }
+        }
+        {   // h list of unit_h[tid]
+            const int unit = F.unit_h[tid];
+            if (unit < 0 || unit >= NA) { ++mismatches; continue; }
+            ++seen_h[unit];
+            const int nh = F.wave_nh[wave], hreg = F.ext ? DSS_HCX : DSS_HC;
+            if (!F.ext && nh > DSS_HC) ++mismatches;
+            std::vector<Blk> got;
+            for (int sl = 0; sl < nh; ++sl) {
+                const int off = F.grp_hoff[grp2] + sl * 32 + (lane & 7) * 4;
+                if (off < 0 || off + 4 > rec_end) { ++oob; continue; }
+                Blk b;
+                b.col = sl < hreg ? (int)((F.h_col[(size_t)(sl >> 2) * NA + tid] >> (8 * (sl & 3))) & 0xFF)
+                                  : (int)hxc[(size_t)grp2 * DSS_HX + (sl - DSS_HCX)];
+                for (int k = 0; k < 4; ++k) b.w[k] = F.hblk[off + k];
+                got.push_back(b);
+            }
+            compare(got, 2 * G + unit / 8, unit & 7);
+        }
+    }
+    for (int u = 0; u < NA; ++u) if (seen_zr[u] != 1 || seen_h[u] != 1) ++mismatches;
+    if ((size_t)F.hfloats * sizeof(float) > DSS_HBLK_BYTES) ++mismatches;
+    info[5] = tails / 8;             // every tail block is seen by the 8 lanes of its row group
+    info[6] = mismatches; info[7] = oob;
+    return DSS_OK;
+}
 
 extern "C" int dss_selftest_exp10(const float *x, const float *comp, float *out, long n)
 {
