@@ -404,6 +404,11 @@ def test_extended_paths_ragged_and_teacher_forced(oracle):
         for t in range(5):
             dec.synthesize(feats[0, t])
         assert np.array_equal(logits, dec.forced_logits)
+        # the other association order of GRU A (tail sums sit before the input term there)
+        blob1 = synthetic_blob(7, gru_a_order=1, skew=0.05)
+        lpcnet.load_model(blob1)
+        assert lpcnet.model_info()["fast_path"] == 2
+        assert np.array_equal(LPCNetBatch(3, 6).synthesize(feats), _oracle_pcm(oracle, blob1, feats))
     finally:
         lpcnet.load_model(synthetic_blob(0))
 
