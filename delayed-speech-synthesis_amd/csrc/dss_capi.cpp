@@ -345,7 +345,7 @@ static void build_fast_layout(const BlobView &v, int NA, FastLayout &F)
     //   int   tail_off[48][2]                float offset of the group's z list and of its r list
     //   uint8 tail_col[48][2][DSS_ZR_TAIL]   block column of every tail slot (96 = unused)
     //   uint8 hx_col[48][DSS_HX]             block column of h slots DSS_HCX.. of the group of the h assignment
-    const int ext_tab_floats = (G * 2 * 4 + G * 2 * DSS_ZR_TAIL + G * DSS_HX) / 4;
+    const int ext_tab_floats = (G * 2 * 4 + G * 2 * DSS_ZR_TAIL + G * DSS_HX) / 4 + 4;     // + 16 B: the kernel reads columns one trip ahead
     std::vector<int> tail_off(G * 2, 0);
     int ext_tab = 0;
     if (fast_ok && ext) {

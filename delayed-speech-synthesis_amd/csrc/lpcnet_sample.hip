@@ -33,14 +33,16 @@
     if constexpr (EXT) if (nh > HC) {                                                            \
         const unsigned char *hx = reinterpret_cast<const unsigned char *>(hblk_lds + m.ext_tab) + \
                                   (NA / 8) * 2 * 4 + (NA / 8) * 2 * DSS_ZR_TAIL + (tid >> 3) * DSS_HX; \
+        unsigned c0 = hx[0], c1 = hx[1];             /* columns are read one trip ahead */      \
         for (int s = HC; s < nh; s += 2) {                                                       \
-            const unsigned c0 = hx[s - HC], c1 = hx[s - HC + 1];                                 \
+            const unsigned c0n = hx[s - HC + 2], c1n = hx[s - HC + 3];                           \
             f32x4 HT[4];                                                                         \
             HT[0] = *reinterpret_cast<const f32x4 *>(hw + s * 128);                              \
             HT[1] = *reinterpret_cast<const f32x4 *>(hw + (s + 1) * 128);                        \
             HT[2] = *reinterpret_cast<const f32x4 *>(xbase + c0 * 16);                           \
             HT[3] = *reinterpret_cast<const f32x4 *>(xbase + c1 * 16);                           \
             DSS_H_MAC(HT)                                                                        \
+            c0 = c0n; c1 = c1n;                                                                  \
         }                                                                                        \
     }
 #include "lpcnet_sample_common.h"
@@ -289,14 +291,17 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                     const char *tz = reinterpret_cast<const char *>(hblk_lds + toff[0]) + (lane & 7) * 16;
                     const char *tr = reinterpret_cast<const char *>(hblk_lds + toff[1]) + (lane & 7) * 16;
                     const char *xb = reinterpret_cast<const char *>(L.state_a[cur]);
+                    unsigned cz = tc[0], cr = tc[DSS_ZR_TAIL];        // the columns of a slot are read one trip ahead
                     for (int s = 0; s < nzt; ++s) {
+                        const unsigned czn = tc[s + 1], crn = tc[DSS_ZR_TAIL + s + 1];   // (one byte past a row: unused)
                         const f32x4 wz = *reinterpret_cast<const f32x4 *>(tz + s * 128);
                         const f32x4 wr = *reinterpret_cast<const f32x4 *>(tr + s * 128);
-                        const f32x4 xz = *reinterpret_cast<const f32x4 *>(xb + (unsigned)tc[s] * 16);
-                        const f32x4 xr = *reinterpret_cast<const f32x4 *>(xb + (unsigned)tc[DSS_ZR_TAIL + s] * 16);
+                        const f32x4 xz = *reinterpret_cast<const f32x4 *>(xb + cz * 16);
+                        const f32x4 xr = *reinterpret_cast<const f32x4 *>(xb + cr * 16);
                         const f32x2 pz0 = wz.lo * xz.lo, pz1 = wz.hi * xz.hi, pr0 = wr.lo * xr.lo, pr1 = wr.hi * xr.hi;
                         az += pz0.x; ar += pr0.x; az += pz0.y; ar += pr0.y;
                         az += pz1.x; ar += pr1.x; az += pz1.y; ar += pr1.y;
+                        cz = czn; cr = crn;
                     }
                 }
                 if (recur_first) { az = gz + az; ar = gr + ar; }
