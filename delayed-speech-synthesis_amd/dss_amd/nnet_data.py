@@ -167,8 +167,30 @@ def convert(path_in: str, path_out: str, names: Optional[Dict[str, str]] = None,
     return len(blob)
 
 
+def kernel_fit(blob: bytes) -> dict:
+    """Which sample-rate kernel the model will run on and how much LDS its image takes, from the host-only layout check
+    of the library (``dss_selftest_fast_layout``: no GPU needed)."""
+    import ctypes
+    from . import _lib
+    L = _lib.load()
+    info = (ctypes.c_int * 8)()
+    _lib.check(L.dss_selftest_fast_layout(blob, len(blob), info))
+    keys = ("fast_path", "zr_blocks_max", "h_blocks_max", "lds_bytes", "zr_register_slots", "tail_blocks", "mismatches", "oob")
+    out = dict(zip(keys, list(info)))
+    out["kernel"] = {0: "generic (GRU A blocks streamed from L2: 3-4x slower)", 1: "CU-resident",
+                     2: "CU-resident with tail paths (some rows exceed the register slots: 1.1-1.6x slower)"}[out["fast_path"]]
+    return out
+
+
 if __name__ == "__main__":
     if len(sys.argv) not in (3, 4):
         sys.exit("usage: python -m dss_amd.nnet_data <nnet_data.c> <out.blob> [gru_a_order: 0 (default, xiph 2021) | 1 (2019-20)]")
     n = convert(sys.argv[1], sys.argv[2], gru_a_order=int(sys.argv[3]) if len(sys.argv) == 4 else 0)
     print(f"wrote {sys.argv[2]}: {n} bytes")
+    try:
+        with open(sys.argv[2], "rb") as f:
+            fit = kernel_fit(f.read())
+        print(f"sample-rate kernel: {fit['kernel']}; z/r blocks per row group <= {fit['zr_blocks_max']}, h blocks <= "
+              f"{fit['h_blocks_max']}, LDS image {fit['lds_bytes']} B")
+    except Exception as e:           # the library may not be built on the machine that converts
+        print(f"(kernel fit not checked: {e})")

@@ -68,3 +68,11 @@ def test_layout_rejects_garbage():
     blob = bytearray(synthetic_blob(0))
     blob[0:4] = b"XXXX"
     assert L.dss_selftest_fast_layout(bytes(blob), len(blob), info) != 0
+
+
+def test_converter_reports_the_kernel_fit():
+    from dss_amd.nnet_data import kernel_fit
+    assert kernel_fit(synthetic_blob(0))["fast_path"] == 1
+    fit = kernel_fit(synthetic_blob(7, skew=0.05))
+    assert fit["fast_path"] == 2 and "tail" in fit["kernel"] and fit["mismatches"] == 0
+    assert kernel_fit(synthetic_blob(7, skew=0.3))["fast_path"] == 0
