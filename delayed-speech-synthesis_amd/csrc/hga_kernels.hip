@@ -39,6 +39,7 @@ __device__ __forceinline__ int hga_win_stop(int start, float wl, int sr)
 // (same stream, consecutive channels), whose input samples are staged through LDS in tiles of HGA_TT rows with
 // 128-byte row segments; lane 2*nsec-1 writes the filtered sample to the column's row buffer at row0 + t.
 #define HGA_TT 64
+#define HGA_WTAB 256          // windows whose row ranges the fused kernel tabulates in LDS (2 KB)
 
 // lanes 1..15 of every row receive their left neighbour's `y`; lane 0 (no neighbour) keeps `x`: the column's input
 __device__ __forceinline__ double hga_shift_in(double x, double y)
@@ -176,6 +177,8 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
     __shared__ double ys[HGA_TT][16];
     __shared__ double coef[16][5];
     __shared__ double dump[256];
+    __shared__ int wtab[2][HGA_WTAB];          // first and one-past-last row of the first HGA_WTAB windows (the float32 /
+                                               //   round() arithmetic of pyx:43-44 once per block instead of once per tile)
     extern __shared__ __attribute__((aligned(16))) double ring[];         // [ring_mask + 1][16]
     const int tid = threadIdx.x, r = tid & 15, pib = tid >> 4;
     const long total = (long)S * C;
@@ -197,6 +200,11 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
     }
     double *zp = zi + (size_t)s * 2 * 8 * 2 * C + c;
     double z0 = zp[((f * 8 + q) * 2 + 0) * (size_t)C], z1 = zp[((f * 8 + q) * 2 + 1) * (size_t)C];
+    for (int w = tid; w < W && w < HGA_WTAB; w += 256) {
+        const int st = hga_win_start(w, ws, sr);
+        wtab[0][w] = st;
+        wtab[1][w] = hga_win_stop(st, wl, sr);
+    }
     // rows [0, row0) of the ring: zeros (CASE 2, pyx:116) or the overlap the previous call left (CASE 3, pyx:123-131)
     for (int idx = tid; idx < row0 * 16; idx += 256) {
         const int rr = idx >> 4, p = idx & 15;
@@ -213,19 +221,26 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
     const int steps = n + nsec2 - 1;
     double y = 0.0;
     int w_next = 0;                                        // first window not yet written (block-uniform)
+    // Input tiles: thread (tt0, p) owns column p of rows tt0, tt0 + 16, ... of every tile.  The next tile's samples are
+    // fetched into registers before the current tile's steps run and go to LDS after them: the HBM latency hides under
+    // the filter arithmetic instead of standing between two barriers.
+    const int lp = tid & 15, ltt = tid >> 4;
+    const long lpp = pair0 + lp;
+    const bool lvalid = lpp < total;
+    const double *lcol = data;
+    if (lvalid) { const int sp = (int)(lpp / C), cp = (int)(lpp - (long)sp * C); lcol = data + (size_t)sp * n * C + cp; }
+    double pre[HGA_TT / 16];
+#define HGA_FETCH(BASE)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < HGA_TT / 16; ++j) {                                    \
+        const int t = (BASE) + ltt + 16 * j;                                                     \
+        pre[j] = (lvalid && t < n) ? lcol[(size_t)t * C] : 0.0;                                  \
+    }
+    HGA_FETCH(0)
     for (int base = 0; base < steps; base += HGA_TT) {
         __syncthreads();                                   // previous tile fully consumed
-        for (int idx = tid; idx < HGA_TT * 16; idx += 256) {
-            const int tt = idx >> 4, p = idx & 15;
-            const long pp = pair0 + p;
-            const int t = base + tt;
-            double v = 0.0;
-            if (t < n && pp < total) {
-                const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
-                v = data[((size_t)sp * n + t) * C + cp];
-            }
-            xs[tt][p] = v;
-        }
+#pragma unroll
+        for (int j = 0; j < HGA_TT / 16; ++j) xs[ltt + 16 * j][lp] = pre[j];
+        if (base + HGA_TT < steps) { HGA_FETCH(base + HGA_TT) }
         __syncthreads();
         const int kend = min(base + HGA_TT, steps);
         int k = base;
@@ -242,6 +257,22 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
             char *yp = ybase + (k - base) * ystride;
             const double *xp = &xs[k - base][pib];
             double xcur = *xp;
+            // four steps per trip with constant LDS offsets (a DPP move is convergent: the compiler will not unroll a loop of
+            // unknown length around it): per step 9 fp64 operations, 2 DPP moves, one LDS read, one LDS write
+            double *const yl = &ys[k - base][pib];
+            int kk = 0;
+            for (; k + 4 <= ksteady; k += 4, kk += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double xnext = xp[16 * (kk + u + 1)];
+                    const double in = hga_shift_in(xcur, y);
+                    HGA_BIQUAD(in)
+                    if (is_last) yl[16 * (kk + u)] = y;
+                    xcur = xnext;
+                }
+            }
+            xp += 16 * kk;
+            yp += kk * ystride;
             for (; k < ksteady; ++k) {
                 xp += 16;
                 const double xnext = *xp;
@@ -276,11 +307,19 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
             const int p = tid & 15, wi = tid >> 4;
             const long pp = pair0 + p;
             for (int w = w_next + wi; w < W; w += 16) {
-                const int start = hga_win_start(w, ws, sr);
-                const int stop = hga_win_stop(start, wl, sr);
+                const int start = w < HGA_WTAB ? wtab[0][w] : hga_win_start(w, ws, sr);
+                const int stop = w < HGA_WTAB ? wtab[1][w] : hga_win_stop(start, wl, sr);
                 if (stop > rows_done) break;
                 double sum = 0.0;
-                for (int rr = start; rr < stop; ++rr) {
+                int rr = start;
+                for (; rr + 8 <= stop; rr += 8) {          // eight ring reads in flight, then their terms in row order
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ring[((rr + u) & ring_mask) * 16 + p];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sum += v[u] * v[u];
+                }
+                for (; rr < stop; ++rr) {
                     const double v = ring[(rr & ring_mask) * 16 + p];
                     sum += v * v;
                 }
@@ -290,7 +329,8 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
                     out[((size_t)sp * W + w) * C + cp] = apply_log ? log(pw) : pw;
                 }
             }
-            while (w_next < W && hga_win_stop(hga_win_start(w_next, ws, sr), wl, sr) <= rows_done) ++w_next;
+            while (w_next < W && (w_next < HGA_WTAB ? wtab[1][w_next] : hga_win_stop(hga_win_start(w_next, ws, sr), wl, sr)) <= rows_done)
+                ++w_next;
         }
     }
     __syncthreads();
