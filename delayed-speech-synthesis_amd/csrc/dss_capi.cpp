@@ -1315,6 +1315,7 @@ extern "C" int dss_hga_set_frontend(dss_hga *h, int c_raw, const int *src_col, c
     for (int c = 0; c < C; ++c)
         if (src_col[c] < 0 || src_col[c] >= c_raw || grid_of[c] >= n_grids) { dss_set_error("front-end column %d out of range", c); return DSS_EINVAL; }
     const int n_comp = n_grids ? comp_off[n_grids] : 0;
+    if (n_comp > 4 * c_raw) { dss_set_error("front end: %d reference columns for %d raw columns", n_comp, c_raw); return DSS_EINVAL; }
     for (int g = 0; g < n_grids; ++g)
         if (comp_off[g + 1] <= comp_off[g]) { dss_set_error("grid %d has no reference channels", g); return DSS_EINVAL; }
     for (int k = 0; k < n_comp; ++k)

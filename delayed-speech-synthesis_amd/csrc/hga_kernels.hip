@@ -519,28 +519,61 @@ hga_frontend_kernel(const double *__restrict__ raw, double *__restrict__ pre, in
                     const int *__restrict__ src_col, const int *__restrict__ grid_of, int n_grids,
                     const int *__restrict__ comp_cols, const int *__restrict__ comp_off)
 {
-    extern __shared__ __attribute__((aligned(16))) double fe_tile[];     // [FE_ROWS][c_raw], then [FE_ROWS][4] means
+    extern __shared__ __attribute__((aligned(16))) double fe_tile[];     // [FE_ROWS][c_raw], [FE_ROWS][4] means, [<= 4 * c_raw] member columns
     double *means = fe_tile + (size_t)FE_ROWS * c_raw;
+    int *cols = reinterpret_cast<int *>(means + FE_ROWS * 4);            // the grids' member columns, in summation order
     const int tid = threadIdx.x;
     const long row_base = (long)blockIdx.x * FE_ROWS;
     const int nrows = (int)min((long)FE_ROWS, (long)total - row_base);
     const double *src = raw + (size_t)row_base * c_raw;
-    for (int idx = tid; idx < nrows * c_raw; idx += 256) fe_tile[idx] = src[idx];       // rows are contiguous: fully coalesced
+    // rows are contiguous: fully coalesced; eight loads per thread in flight (a loop of unknown length is not unrolled,
+    // and one load per trip would expose the HBM latency sixteen times per tile)
+    const int n_el = nrows * c_raw;
+    for (int base = 0; base < n_el; base += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int idx = base + u * 256 + tid; v[u] = idx < n_el ? src[idx] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int idx = base + u * 256 + tid; if (idx < n_el) fe_tile[idx] = v[u]; }
+    }
+    for (int k = tid; k < comp_off[n_grids]; k += 256) cols[k] = comp_cols[k];
     __syncthreads();
     if (tid < nrows * n_grids) {
         const int rr = tid / n_grids, g = tid - rr * n_grids;
         const double *row = fe_tile + (size_t)rr * c_raw;
         const int a = comp_off[g], b2 = comp_off[g + 1];
         double sum = 0.0;
-        for (int k = a; k < b2; ++k) sum += row[comp_cols[k]];
+        int k = a;
+        for (; k + 8 <= b2; k += 8) {              // eight members' reads in flight, then their terms in list order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[cols[k + u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; k < b2; ++k) sum += row[cols[k]];
         means[rr * 4 + g] = sum / (double)(b2 - a);
     }
     __syncthreads();
-    for (int idx = tid; idx < nrows * C; idx += 256) {
-        const int rr = idx / C, c = idx - rr * C;
-        const int g = grid_of[c];
-        const double v = fe_tile[(size_t)rr * c_raw + src_col[c]];
-        pre[((size_t)row_base + rr) * C + c] = g >= 0 ? v - means[rr * 4 + g] : v;
+    const int n_out = nrows * C;                    // eight independent elements per thread and trip, as for the loads
+    for (int base = 0; base < n_out; base += 8 * 256) {
+        double o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            o[u] = 0.0;
+            if (idx < n_out) {
+                const int rr = idx / C, c = idx - rr * C;
+                const int g = grid_of[c];
+                const double v = fe_tile[(size_t)rr * c_raw + src_col[c]];
+                o[u] = g >= 0 ? v - means[rr * 4 + g] : v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < n_out) pre[(size_t)row_base * C + idx] = o[u];
+        }
     }
 }
 
@@ -548,7 +581,7 @@ int dss_launch_hga_frontend(const double *d_raw, double *d_pre, int S, int n, in
                             const int *grid_of, int n_grids, const int *comp_cols, const int *comp_off, hipStream_t st)
 {
     const int total = S * n;
-    const size_t lds = ((size_t)FE_ROWS * c_raw + FE_ROWS * 4) * sizeof(double);
+    const size_t lds = ((size_t)FE_ROWS * c_raw + FE_ROWS * 4) * sizeof(double) + (size_t)4 * c_raw * sizeof(int);   // member lists: at most 4 grids of c_raw columns
     if (lds > 64 * 1024 || n_grids > 4) { dss_set_error("front end: %d raw columns / %d grids exceed the tile", c_raw, n_grids); return DSS_EINVAL; }
     hipLaunchKernelGGL(hga_frontend_kernel, dim3((total + FE_ROWS - 1) / FE_ROWS), dim3(256), lds, st, d_raw, d_pre, total, c_raw, C,
                        src_col, grid_of, n_grids, comp_cols, comp_off);
