@@ -619,7 +619,7 @@ struct dss_lpcnet_batch {
     DssBatchDev d;
     int last_utts = 0, last_frames = 0;
     int trace = 0, timing = 0;
-    int multi = 0;                // 0 auto, -1 never, 3/4 forced utterances per workgroup (dss_lpcnet_batch_set_multi)
+    int pair = 0;                 // 0 auto, -1 never, 2 always: two utterances per workgroup (dss_lpcnet_batch_set_multi)
     float *d_feat = nullptr;      // staging for the host-buffer entry point
     short *d_pcm = nullptr;
     int *d_slots = nullptr;       // [max_utts] slot list of a ragged call
@@ -776,9 +776,9 @@ extern "C" int dss_lpcnet_batch_set_multi(dss_lpcnet_batch *b, int utterances_pe
 {
     if (!b) return DSS_EINVAL;
     const int u = utterances_per_workgroup;
-    if (!(u == 0 || u == -1 || u == 3 || u == 4)) { dss_set_error("utterances per workgroup: 0 (auto), -1 (off), 3 or 4"); return DSS_EINVAL; }
-    if (u >= 3 && u > dss_multi_max_u(*b->model)) { dss_set_error("%d utterances per workgroup do not fit beside this model in LDS", u); return DSS_EINVAL; }
-    b->multi = u;
+    if (!(u == 0 || u == -1 || u == 1 || u == 2)) { dss_set_error("utterances per workgroup: 0 (auto), 1 or -1 (always one), 2 (always two)"); return DSS_EINVAL; }
+    if (u == 2 && !dss_pair_fits(*b->model)) { dss_set_error("two utterances per workgroup do not fit beside this model in LDS (or it needs the extended paths)"); return DSS_EINVAL; }
+    b->pair = u == 1 ? -1 : u;
     return DSS_OK;
 }
 
@@ -817,7 +817,7 @@ static int run_batch(dss_lpcnet_batch *b, const float *d_features, int n_utts, i
     int rc = dss_launch_frame_network(*b->model, b->d, d_features, n_utts, n_frames, feat_stride, s);
     if (rc) return rc;
     if (b->timing) DSS_HIP_CHECK(hipEventRecord(b->ev[1], s));
-    rc = dss_launch_sample_network(*b->model, b->d, n_utts, n_frames, d_pcm, b->trace, b->multi, s);
+    rc = dss_launch_sample_network(*b->model, b->d, n_utts, n_frames, d_pcm, b->trace, b->pair, s);
     if (rc) return rc;
     if (b->timing) {
         DSS_HIP_CHECK(hipEventRecord(b->ev[2], s));

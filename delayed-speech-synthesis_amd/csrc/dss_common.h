@@ -134,13 +134,13 @@ struct DssBatchDev {
 // kernels (defined in the .hip files)
 int dss_launch_frame_network(const DssModelDev &m, DssBatchDev &b, const float *d_features, int n_utts, int n_frames,
                              int feat_stride, hipStream_t s);
-// multi: 0 = choose (throughput kernel when the call has more utterances than the chip has CUs), -1 = never,
-// 3 / 4 = force that many utterances per workgroup
+// pair: 0 = choose (two utterances per workgroup when the call has more utterances than the chip has CUs), -1 = never,
+// 2 = always (uniform calls of models that fit, see dss_pair_fits)
 int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
-                              int trace, int multi, hipStream_t s);
-int dss_launch_sample_network_multi(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm, int U,
-                                    int stamp, hipStream_t s);
-int dss_multi_max_u(const DssModelDev &m);
+                              int trace, int pair, hipStream_t s);
+int dss_launch_sample_network_pair(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm, int trace,
+                                   hipStream_t s);
+int dss_pair_fits(const DssModelDev &m);
 int dss_launch_sample_network_generic(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
                                       int trace, hipStream_t s);
 int dss_launch_exp10_selftest(const float *d_x, const float *d_comp, float *d_out, long n, hipStream_t s);

@@ -97,34 +97,7 @@ struct SampleLds {
         acc += p1.y;                                                                             \
     }
 
-// Tree walk over the 256 decision bits the dual-FC waves left in L.bits: every operand is wave-uniform, so this is scalar
-// bit arithmetic.  8 levels, 3 scalar instructions each: test the node's bit (s_bitcmp1_b64 -> SCC), val = 2*val + SCC
-// (s_addc_u32), next node index.  Nodes 1..63 live in m0, 64..127 in m1, 128..191 in m2, 192..255 in m3.
-#define DSS_TREE_WALK(VAL)                                                                       \
-    {                                                                                            \
-        const uint4 b0 = *reinterpret_cast<const uint4 *>(&L.bits[0]);                           \
-        const uint4 b1 = *reinterpret_cast<const uint4 *>(&L.bits[4]);                           \
-        const unsigned long long m0 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.x); \
-        const unsigned long long m1 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.z); \
-        const unsigned long long m2 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.x); \
-        const unsigned long long m3 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.z); \
-        int tnode_;                                                                              \
-        unsigned long long mm_;                                                                  \
-        asm volatile(                                                                            \
-            "s_mov_b32 %0, 0\n\t"                                                                \
-            "s_bitcmp1_b64 %3, 1\n\t"          "s_addc_u32 %0, %0, %0\n\t"                       \
-            "s_or_b32 %1, %0, 2\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
-            "s_or_b32 %1, %0, 4\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
-            "s_or_b32 %1, %0, 8\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
-            "s_or_b32 %1, %0, 16\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
-            "s_or_b32 %1, %0, 32\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
-            "s_bitcmp1_b64 %4, %0\n\t"         "s_addc_u32 %0, %0, %0\n\t"                       \
-            "s_cmp_lt_u32 %0, 64\n\t"          "s_cselect_b64 %2, %5, %6\n\t"                    \
-            "s_bitcmp1_b64 %2, %0\n\t"         "s_addc_u32 %0, %0, %0"                            \
-            : "=&s"(VAL), "=&s"(tnode_), "=&s"(mm_)                                              \
-            : "s"(m0), "s"(m1), "s"(m2), "s"(m3)                                                 \
-            : "scc");                                                                            \
-    }
+#define DSS_TREE_WALK(VAL) DSS_TREE_WALK_AT(VAL, L.bits)
 
 // one candidate excitation value of the speculation, for wave 6 (inputs published by wave 7 right after its tree walk)
 #define DSS_SPECULATE(CAND)                                                                      \
@@ -642,37 +615,29 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     }
 }
 
-// Which kernel serves a uniform, untraced call of n utterances.  One utterance per workgroup takes `rounds1` rounds of
-// 256 workgroups at ~6.4 k cycles per sample; U utterances per workgroup finish one utterance-sample per ~3.3 k-cycle slot
-// (DESIGN.md 5), i.e. U slots per sample of each of its utterances.
-static int choose_multi(const DssModelDev &m, int n_utts, int multi)
+// Number of CUs of the current device, asked once per device (the eager streaming tick launches this kernel every 40 ms).
+static int dss_cu_count()
 {
-    const int umax = dss_multi_max_u(m);
-    if (multi < 0 || umax == 0) return 0;
-    if (multi >= 3) return multi <= umax ? multi : 0;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return 0;                                                // automatic choice is off until the throughput form measures faster
-    if (n_utts <= cus) return 0;                             // the latency kernel already has a CU per utterance
-    const double cost1 = (double)((n_utts + cus - 1) / cus) * 6.4;
-    int best = 0;
-    double best_cost = cost1;
-    for (int U = 3; U <= umax; ++U) {
-        const int wgs = (n_utts + U - 1) / U;
-        const double c = (double)((wgs + cus - 1) / cus) * U * 3.3;
-        if (c < best_cost) { best_cost = c; best = U; }
-    }
-    return best;
+    static std::mutex mu;
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    int &c = cached[dev & 63];
+    if (!c && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
+    return c;
 }
 
 int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm, int trace,
-                              int multi, hipStream_t s)
+                              int pair, hipStream_t s)
 {
     if (!m.fast_ok || trace >= 16) return dss_launch_sample_network_generic(m, b, n_utts, n_frames, d_pcm, trace & 15, s);
-    if ((!trace || (trace == 2 && multi >= 3)) && !b.slot_of && !b.count_of) {     // trace 2 = phase stamps (diagnostic)
-        const int U = choose_multi(m, n_utts, multi);
-        if (U) return dss_launch_sample_network_multi(m, b, n_utts, n_frames, d_pcm, U, trace == 2, s);
-    }
+    // Uniform calls with more utterances than the chip has CUs run two utterances per workgroup (lpcnet_sample_pair.hip:
+    // the same roles with the utterances as the halves of packed fp32 instructions); with a CU per utterance the
+    // one-utterance form below is faster.  pair: 0 = this rule, -1 = never, 2 = always (tests, A/B timing).
+    if (pair >= 0 && trace <= 2 && !b.slot_of && !b.count_of && dss_pair_fits(m) &&
+        (pair == 2 || (!trace && n_utts > 128 && n_utts > dss_cu_count())))
+        return dss_launch_sample_network_pair(m, b, n_utts, n_frames, d_pcm, trace, s);
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
     // two register-slot capacities are compiled: 10 per gate (no spills) and 12 (a few spilled registers)
     const bool z10 = m.zr_cap <= 10;

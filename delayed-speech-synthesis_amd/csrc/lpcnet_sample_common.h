@@ -1,6 +1,6 @@
 // csrc/lpcnet_sample_common.h -- register-level building blocks shared by the two CU-resident sample-rate kernels
-// (lpcnet_sample.hip: one utterance per workgroup, latency-optimised; lpcnet_sample_multi.hip: several utterances per
-// workgroup in a software pipeline, throughput-optimised).  Every macro keeps the summation order of xiph's
+// (lpcnet_sample.hip: one utterance per workgroup, latency-optimised; lpcnet_sample_pair.hip: two utterances per
+// workgroup as the halves of packed fp32 instructions, throughput-optimised).  Every macro keeps the summation order of xiph's
 // sparse_sgemv_accum8x4 / sgemv_accum (src/vec.h generic path): one product at a time, ascending input.
 #pragma once
 #include "dss_common.h"
@@ -175,5 +175,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
             }                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
+    }
+
+// Tree walk over the 256 decision bits the dual-FC waves left in BITS (8 words): every operand is wave-uniform, so this is scalar
+// bit arithmetic.  8 levels, 3 scalar instructions each: test the node's bit (s_bitcmp1_b64 -> SCC), val = 2*val + SCC
+// (s_addc_u32), next node index.  Nodes 1..63 live in m0, 64..127 in m1, 128..191 in m2, 192..255 in m3.
+#define DSS_TREE_WALK_AT(VAL, BITS)                                                                       \
+    {                                                                                            \
+        const uint4 b0 = *reinterpret_cast<const uint4 *>(&(BITS)[0]);                           \
+        const uint4 b1 = *reinterpret_cast<const uint4 *>(&(BITS)[4]);                           \
+        const unsigned long long m0 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.x); \
+        const unsigned long long m1 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b0.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b0.z); \
+        const unsigned long long m2 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.x); \
+        const unsigned long long m3 = ((unsigned long long)__builtin_amdgcn_readfirstlane(b1.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(b1.z); \
+        int tnode_;                                                                              \
+        unsigned long long mm_;                                                                  \
+        asm volatile(                                                                            \
+            "s_mov_b32 %0, 0\n\t"                                                                \
+            "s_bitcmp1_b64 %3, 1\n\t"          "s_addc_u32 %0, %0, %0\n\t"                       \
+            "s_or_b32 %1, %0, 2\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_or_b32 %1, %0, 4\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_or_b32 %1, %0, 8\n\t"           "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_or_b32 %1, %0, 16\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_or_b32 %1, %0, 32\n\t"          "s_bitcmp1_b64 %3, %1\n\t"   "s_addc_u32 %0, %0, %0\n\t" \
+            "s_bitcmp1_b64 %4, %0\n\t"         "s_addc_u32 %0, %0, %0\n\t"                       \
+            "s_cmp_lt_u32 %0, 64\n\t"          "s_cselect_b64 %2, %5, %6\n\t"                    \
+            "s_bitcmp1_b64 %2, %0\n\t"         "s_addc_u32 %0, %0, %0"                            \
+            : "=&s"(VAL), "=&s"(tnode_), "=&s"(mm_)                                              \
+            : "s"(m0), "s"(m1), "s"(m2), "s"(m3)                                                 \
+            : "scc");                                                                            \
     }
 

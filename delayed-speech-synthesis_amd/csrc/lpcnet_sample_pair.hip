@@ -1,0 +1,820 @@
+// csrc/lpcnet_sample_pair.hip -- LPCNet sample-rate network, throughput form: TWO utterances per persistent
+// workgroup, carried as the two halves of packed fp32 instructions (gfx950).
+//
+// Same algorithm, same roles and barriers, same weight placement as lpcnet_sample.hip (xiph/LPCNet src/lpcnet.c
+// lpcnet_synthesize_tail_impl() + run_sample_network(), src/nnet.c compute_gru_a_input / compute_sparse_gru / compute_gruB /
+// sample_mdense, generic float path of src/vec.h; reached through extensions/lpcnet/cLPCNet.pxd:13 and, in bulk, through
+// local/training.py:165-207).  What changes is the unit of work of an instruction: where the latency kernel adds one
+// product of utterance A to one running sum, this kernel adds the products of utterances A and B to their two running
+// sums with one v_pk_add_f32, and forms them with one v_pk_mul_f32 whose weight operand is broadcast to both halves
+// (op_sel / op_sel_hi on src0).  Each half of a packed instruction is an ordinary IEEE fp32 operation, rounded on its
+// own, and every chain keeps the C source's order (one product at a time, ascending input; -ffp-contract=off), so both
+// utterances come out bit-identical to the scalar C path -- and to the latency kernel, whose decoder state they share.
+//
+// Why it pays: the CU-resident weights (VGPRs, LDS) are read once for two utterances, and a lone wave issues a packed
+// instruction as fast as a plain one (tools/ubench/simd_share.hip: 4.9 cycles per instruction with two chains), so the
+// serial path of a sample step does twice the work in about 1.2x the time.  The state vectors live in LDS as (A, B)
+// pairs, so one ds_read_b128 feeds two inputs of both utterances.  Packed results are never formed ahead into
+// registers (the latency kernel's 64..96 product registers): the chains multiply as they go, the multiplications of
+// the next block sit in the dependent-latency shadow of the current block's sums.
+//
+// The compiler does not fold a broadcast into op_sel (it copies the weight into a register pair instead, which would
+// double the weight registers), so the products are inline asm; the sum chains whose order of issue matters (one
+// dependent chain per lane: h gate, GRU B) are fixed-order asm blocks of one 8x4 block each.
+#include <mutex>
+
+#include "lpcnet_sample_common.h"
+#undef HC
+
+#define PGB6 192                          // GRU B inputs whose weights sit in wave 6's VGPRs (0..191)
+#define PGB7 128                          // ... in wave 7's VGPRs (192..319)
+#define PGBL (NA - PGB6 - PGB7)           // ... and the last 64 inputs' weights in LDS, [row][PGL_STRIDE]
+#define PGL_STRIDE 68
+#define DSS_PAIR_HBLK_BYTES 131840        // dynamic LDS left beside PairLds (160 KB per CU)
+
+struct PairLds {
+    float state_a[2][2 * (NA + 4)];       // double-buffered GRU A state, [unit][utterance]; "column 96" = eight zeros
+    float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
+    float gb_wl[NB3 * PGL_STRIDE];        // GRU B input weights of the last PGBL inputs, row-major
+    float tansig[208];
+    float ulaw2lin[256];
+    float spec_tab_pred[2][256];          // speculation over all 256 excitation values, per utterance:
+    unsigned short spec_tab_idx[2][256];  //   next sample's prediction and its two mu-law indices (su | pu << 8)
+    float spec_prod[DSS_LPC_ORDER][2];    // inputs of the speculation, published by wave 7: [0] = lpc[0] of the next sample's
+                                          //   frame, [j] = history[j-1] * lpc[j] (the products are the same for every candidate)
+    float spec_pred[2];                   //   and this sample's prediction
+    float pad1[2];
+    float gb_acc[64][2];                  // GRU B partial sums handed from wave 6 to wave 7
+    float ah[NA][2];                      // h-gate pre-activation: written by a unit's h lane, read by its z/r lane
+    float state_b[NB][2];
+    float thr[2][8];
+    unsigned bits[2][8];                  // decision bit of every tree node (256 bits) per utterance
+    int idx[2][4];                        // last_sig_ulaw, pred_ulaw, last_exc (first sample of a call)
+    int gb_flag;                          // sequence number of the sample whose gb_acc is valid
+    int pad[3];
+    short pcm[2][DSS_FRAME_SIZE];
+};
+static_assert(sizeof(PairLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
+static_assert(sizeof(PairLds) + DSS_PAIR_HBLK_BYTES <= 160 * 1024, "LDS budget");
+
+// ---- packed fp32 with a broadcast weight --------------------------------------------------------------------------
+// (w.x * x.x, w.x * x.y) and (w.y * x.x, w.y * x.y): src0 low half (high half) to both lanes of the packed multiply
+__device__ __forceinline__ f32x2 dss_pk_mul_lo(f32x2 w, f32x2 x)
+{
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(x));
+    return r;
+}
+__device__ __forceinline__ f32x2 dss_pk_mul_hi(f32x2 w, f32x2 x)
+{
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "v"(x));
+    return r;
+}
+// One 8x4 block (or four consecutive dense inputs) of ONE dependent chain, software-pipelined: the four sums of this
+// block's products P (formed one step earlier, in place, where the inputs were) alternate with the four products of
+// the NEXT block, X <- W * X, so that every dependent v_pk_add_f32 (8.9 cycles of latency) has an independent
+// multiplication behind it.  W = (w0, w1) (w2, w3); X0..X3 = the (A, B) pairs of inputs 0..3.
+#define DSS_PK_STEP4(ACC, P0, P1, P2, P3, X0, X1, X2, X3, WLO, WHI)                              \
+    asm("v_pk_add_f32 %[a], %[a], %[p0]\n\t"                                                     \
+        "v_pk_mul_f32 %[x0], %[wl], %[x0] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_add_f32 %[a], %[a], %[p1]\n\t"                                                     \
+        "v_pk_mul_f32 %[x1], %[wl], %[x1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_add_f32 %[a], %[a], %[p2]\n\t"                                                     \
+        "v_pk_mul_f32 %[x2], %[wh], %[x2] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_add_f32 %[a], %[a], %[p3]\n\t"                                                     \
+        "v_pk_mul_f32 %[x3], %[wh], %[x3] op_sel:[1,0] op_sel_hi:[1,1]"                          \
+        : [a] "+v"(ACC), [x0] "+v"(X0), [x1] "+v"(X1), [x2] "+v"(X2), [x3] "+v"(X3)              \
+        : [p0] "v"(P0), [p1] "v"(P1), [p2] "v"(P2), [p3] "v"(P3), [wl] "v"(WLO), [wh] "v"(WHI))
+// the first block's products (nothing to add yet) and the last block's sums (nothing left to multiply)
+#define DSS_PK_MUL4(X0, X1, X2, X3, WLO, WHI)                                                    \
+    asm("v_pk_mul_f32 %[x0], %[wl], %[x0] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[x1], %[wl], %[x1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_mul_f32 %[x2], %[wh], %[x2] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[x3], %[wh], %[x3] op_sel:[1,0] op_sel_hi:[1,1]"                          \
+        : [x0] "+v"(X0), [x1] "+v"(X1), [x2] "+v"(X2), [x3] "+v"(X3)                             \
+        : [wl] "v"(WLO), [wh] "v"(WHI))
+#define DSS_PK_ADD4(ACC, P0, P1, P2, P3)                                                         \
+    asm("v_pk_add_f32 %[a], %[a], %[p0]\n\t"                                                     \
+        "v_pk_add_f32 %[a], %[a], %[p1]\n\t"                                                     \
+        "v_pk_add_f32 %[a], %[a], %[p2]\n\t"                                                     \
+        "v_pk_add_f32 %[a], %[a], %[p3]"                                                         \
+        : [a] "+v"(ACC)                                                                          \
+        : [p0] "v"(P0), [p1] "v"(P1), [p2] "v"(P2), [p3] "v"(P3))
+// One 8x4 block of the z gate and one of the r gate: two independent chains, so the sums of one hide the latency of the
+// other and the products need no pipelining across blocks (they are formed in place, where the inputs were).
+#define DSS_PK_ZR4(AZ, AR, XZ0, XZ1, XZ2, XZ3, XR0, XR1, XR2, XR3, WZLO, WZHI, WRLO, WRHI)       \
+    asm("v_pk_mul_f32 %[z0], %[wzl], %[z0] op_sel_hi:[0,1]\n\t"                                  \
+        "v_pk_mul_f32 %[r0], %[wrl], %[r0] op_sel_hi:[0,1]\n\t"                                  \
+        "v_pk_mul_f32 %[z1], %[wzl], %[z1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                     \
+        "v_pk_mul_f32 %[r1], %[wrl], %[r1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                     \
+        "v_pk_add_f32 %[az], %[az], %[z0]\n\t"                                                   \
+        "v_pk_add_f32 %[ar], %[ar], %[r0]\n\t"                                                   \
+        "v_pk_mul_f32 %[z2], %[wzh], %[z2] op_sel_hi:[0,1]\n\t"                                  \
+        "v_pk_mul_f32 %[r2], %[wrh], %[r2] op_sel_hi:[0,1]\n\t"                                  \
+        "v_pk_add_f32 %[az], %[az], %[z1]\n\t"                                                   \
+        "v_pk_add_f32 %[ar], %[ar], %[r1]\n\t"                                                   \
+        "v_pk_mul_f32 %[z3], %[wzh], %[z3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                     \
+        "v_pk_mul_f32 %[r3], %[wrh], %[r3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                     \
+        "v_pk_add_f32 %[az], %[az], %[z2]\n\t"                                                   \
+        "v_pk_add_f32 %[ar], %[ar], %[r2]\n\t"                                                   \
+        "v_pk_add_f32 %[az], %[az], %[z3]\n\t"                                                   \
+        "v_pk_add_f32 %[ar], %[ar], %[r3]"                                                       \
+        : [az] "+v"(AZ), [ar] "+v"(AR), [z0] "+v"(XZ0), [z1] "+v"(XZ1), [z2] "+v"(XZ2), [z3] "+v"(XZ3),  \
+          [r0] "+v"(XR0), [r1] "+v"(XR1), [r2] "+v"(XR2), [r3] "+v"(XR3)                         \
+        : [wzl] "v"(WZLO), [wzh] "v"(WZHI), [wrl] "v"(WRLO), [wrh] "v"(WRHI))
+// One input of the two dual-FC layers for both utterances: S0 += w0 * (bA, bB), S1 += w1 * (bA, bB); four inputs per block
+#define DSS_PK_FC4(S0, S1, T0, T1, T2, T3, U0, U1, U2, U3, W0, W1, W2, W3)                       \
+    asm("v_pk_mul_f32 %[t0], %[w0], %[u0] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[u0], %[w0], %[u0] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_mul_f32 %[t1], %[w1], %[u1] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[u1], %[w1], %[u1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_add_f32 %[s0], %[s0], %[t0]\n\t"                                                   \
+        "v_pk_add_f32 %[s1], %[s1], %[u0]\n\t"                                                   \
+        "v_pk_mul_f32 %[t2], %[w2], %[u2] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[u2], %[w2], %[u2] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_add_f32 %[s0], %[s0], %[t1]\n\t"                                                   \
+        "v_pk_add_f32 %[s1], %[s1], %[u1]\n\t"                                                   \
+        "v_pk_mul_f32 %[t3], %[w3], %[u3] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[u3], %[w3], %[u3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_add_f32 %[s0], %[s0], %[t2]\n\t"                                                   \
+        "v_pk_add_f32 %[s1], %[s1], %[u2]\n\t"                                                   \
+        "v_pk_add_f32 %[s0], %[s0], %[t3]\n\t"                                                   \
+        "v_pk_add_f32 %[s1], %[s1], %[u3]"                                                       \
+        : [s0] "+v"(S0), [s1] "+v"(S1), [t0] "=&v"(T0), [t1] "=&v"(T1), [t2] "=&v"(T2), [t3] "=&v"(T3),  \
+          [u0] "+v"(U0), [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3)                             \
+        : [w0] "v"(W0), [w1] "v"(W1), [w2] "v"(W2), [w3] "v"(W3))
+
+// vec.h tanh_approx on an (A, B) pair: per half exactly the operations of dss_tanh_approx, in its order
+__device__ __forceinline__ f32x2 dss_tanh_pk(const float *tab, f32x2 x)
+{
+    const bool n0 = x.x < 0, n1 = x.y < 0;
+    f32x2 a = {n0 ? -x.x : x.x, n1 ? -x.y : x.y};
+    const f32x2 sg = {n0 ? -1.f : 1.f, n1 ? -1.f : 1.f};
+    const f32x2 t = .5f + 25 * a;
+    int i0 = (int)floorf(t.x), i1 = (int)floorf(t.y);
+    i0 = i0 < 0 ? 0 : i0; i0 = i0 > 200 ? 200 : i0;
+    i1 = i1 < 0 ? 0 : i1; i1 = i1 > 200 ? 200 : i1;
+    const f32x2 y = {tab[i0], tab[i1]};
+    a -= .04f * (f32x2){(float)i0, (float)i1};
+    const f32x2 dy = 1 - y * y;
+    const f32x2 r = y + a * dy * (1 - y * a);
+    return sg * r;
+}
+__device__ __forceinline__ f32x2 dss_sigmoid_pk(const float *tab, f32x2 x) { return .5f + .5f * dss_tanh_pk(tab, .5f * x); }
+
+// a pair buffer of one 8x4 block: the block's four inputs for both utterances (two ds_read_b128)
+struct PairX { f32x2 v[4]; };
+__device__ __forceinline__ void dss_pair_loadx(PairX &q, const char *p)
+{
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), c = *reinterpret_cast<const f32x4 *>(p + 16);
+    q.v[0] = a.lo; q.v[1] = a.hi; q.v[2] = c.lo; q.v[3] = c.hi;
+}
+
+// Speculation for one candidate excitation value and both utterances: the output sample, the next LPC prediction (the
+// reference's 16 sequential subtractions; the products history[j-1] * lpc[j] do not depend on the candidate and come
+// from wave 7) and both mu-law indices.  Same expressions, same order as lpcnet_synthesize_tail_impl().
+__device__ __forceinline__ void dss_pair_speculate(PairLds &L, int cand, float u2l_c)
+{
+    const f32x2 sp = *reinterpret_cast<const f32x2 *>(L.spec_pred);
+    const f32x2 pcm_c = sp + u2l_c;
+    f32x4 q = *reinterpret_cast<const f32x4 *>(&L.spec_prod[0][0]);
+    f32x2 pc = 0.f - pcm_c * q.lo;
+    pc -= q.hi;
+#pragma unroll
+    for (int k = 1; k < DSS_LPC_ORDER / 2; ++k) {
+        q = *reinterpret_cast<const f32x4 *>(&L.spec_prod[2 * k][0]);
+        pc -= q.lo;
+        pc -= q.hi;
+    }
+    const int su0 = dss_lin2ulaw(pcm_c.x), su1 = dss_lin2ulaw(pcm_c.y);
+    const int pu0 = dss_lin2ulaw(pc.x), pu1 = dss_lin2ulaw(pc.y);
+    L.spec_tab_pred[0][cand] = pc.x;
+    L.spec_tab_pred[1][cand] = pc.y;
+    L.spec_tab_idx[0][cand] = (unsigned short)(su0 | (pu0 << 8));
+    L.spec_tab_idx[1][cand] = (unsigned short)(su1 | (pu1 << 8));
+}
+
+// what a workgroup runs: utterance rows ua and ub of the call (ub == ua and !has_b: a single utterance, the B halves
+// compute a copy that is never stored)
+struct PairJob { int ua, ub; bool has_b; int fc0; };
+// The two utterances of a workgroup run as one packed job when both exist and have the same number of silent frames
+// ahead of them (frame_count < FEATURES_DELAY: fresh decoders); otherwise one after the other, each with its copy in
+// the B halves.  All fields are wave-uniform.
+struct PairPlan { int u0, fa, fb, n_jobs; bool packed; };
+__device__ __forceinline__ PairJob dss_pair_job(const PairPlan &p, int jn)
+{
+    if (p.n_jobs == 1) return PairJob{p.u0, p.packed ? p.u0 + 1 : p.u0, p.packed, p.fa};
+    return jn == 0 ? PairJob{p.u0, p.u0, false, p.fa} : PairJob{p.u0 + 1, p.u0 + 1, false, p.fb};
+}
+
+// decoder state of the job's utterances into LDS (all 512 threads), followed by a barrier at the caller
+__device__ __forceinline__ void dss_pair_job_init(PairLds &L, const DssBatchDev &b, const PairJob &j, int tid)
+{
+    if (tid < NA) {
+        f32x2 s = {b.gru_a_state[(size_t)j.ua * NA + tid], b.gru_a_state[(size_t)j.ub * NA + tid]};
+        *reinterpret_cast<f32x2 *>(&L.state_a[0][2 * tid]) = s;
+    }
+    if (tid < 16) L.state_a[tid >> 3][2 * NA + (tid & 7)] = 0.f;
+    if (tid < NB) {
+        f32x2 s = {b.gru_b_state[(size_t)j.ua * NB + tid], b.gru_b_state[(size_t)j.ub * NB + tid]};
+        *reinterpret_cast<f32x2 *>(&L.state_b[tid][0]) = s;
+    }
+    if (tid == 0) L.gb_flag = 0;
+}
+
+// h-gate chain of one lane for both utterances: rbh + dgh*st, then its row group's blocks in idx order.  Block
+// records (LDS image) and state pairs are fetched two blocks ahead of the block being summed.
+#define DSS_PH_LOAD(S, BUF)                                                                      \
+    {                                                                                            \
+        HW[BUF] = *reinterpret_cast<const f32x4 *>(hw + (S) * 128);                              \
+        dss_pair_loadx(HX[BUF], xbase + DSS_H_COL(S) * 32);                                      \
+    }
+#define DSS_PH_STEP(S)                                                                           \
+    DSS_PK_STEP4(ah, HX[(S) % 3].v[0], HX[(S) % 3].v[1], HX[(S) % 3].v[2], HX[(S) % 3].v[3],     \
+                 HX[((S) + 1) % 3].v[0], HX[((S) + 1) % 3].v[1], HX[((S) + 1) % 3].v[2], HX[((S) + 1) % 3].v[3], \
+                 HW[((S) + 1) % 3].lo, HW[((S) + 1) % 3].hi)
+#define DSS_PH_CHAIN(XBUF)                                                                       \
+    {                                                                                            \
+        const char *xbase = reinterpret_cast<const char *>(XBUF);                                \
+        f32x4 HW[3];                                                                             \
+        PairX HX[3];                                                                             \
+        f32x2 ah = rbh2 + dgh2 * *reinterpret_cast<const f32x2 *>(xbase + uh * 8);               \
+        DSS_PH_LOAD(0, 0)                                                                        \
+        DSS_PH_LOAD(1, 1)                                                                        \
+        DSS_PK_MUL4(HX[0].v[0], HX[0].v[1], HX[0].v[2], HX[0].v[3], HW[0].lo, HW[0].hi);         \
+        /* nh is even: blocks s and s+1 exist whenever s < nh, one test per pair.  (No break: the asm blocks are      \
+           convergent calls, and a loop with a data-dependent exit around them is not unrolled.) */                 \
+        _Pragma("unroll") for (int s = 0; s < HC; s += 2) {                                      \
+            if (s < nh) {                                                                        \
+                const bool more = s + 2 < HC && s + 2 < nh;                                      \
+                if (more) DSS_PH_LOAD(s + 2 < HC ? s + 2 : 0, (s + 2) % 3)                       \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                DSS_PH_STEP(s);                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                if (more) {                                                                      \
+                    DSS_PH_LOAD(s + 3 < HC ? s + 3 : 0, (s + 3) % 3)                             \
+                    __builtin_amdgcn_sched_barrier(0);                                           \
+                    DSS_PH_STEP(s + 1);                                                          \
+                } else {                                                                         \
+                    DSS_PK_ADD4(ah, HX[(s + 1) % 3].v[0], HX[(s + 1) % 3].v[1], HX[(s + 1) % 3].v[2], HX[(s + 1) % 3].v[3]); \
+                }                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+            }                                                                                    \
+        }                                                                                        \
+        *reinterpret_cast<f32x2 *>(&L.ah[uh][0]) = ah;                                           \
+    }
+
+// GRU B: the chain of one row for both utterances over NBLK blocks of four inputs.  Blocks below G0 take their weights
+// from this lane's registers (WB[k] = inputs 2k, 2k+1), blocks from G0 on from LDS (row-major records, fetched with the
+// state pairs); the new GRU A state pairs come from LDS (same address in every lane: broadcast).  Everything is fetched
+// three blocks ahead of the block being summed; DSS_PGB_HEAD issues the first three fetches (wave 7: under its wait).
+#define DSS_PGB_LOAD(G, G0)                                                                      \
+    {                                                                                            \
+        dss_pair_loadx(GX[(G) & 3], an + 32 * (G));                                              \
+        if ((G) >= (G0)) TW[(G) & 3] = *reinterpret_cast<const f32x4 *>(wl + 16 * ((G) - (G0))); \
+    }
+#define DSS_PGB_WLO(G, G0) ((G) < (G0) ? WB[(G) < (G0) ? 2 * (G) : 0] : TW[(G) & 3].lo)
+#define DSS_PGB_WHI(G, G0) ((G) < (G0) ? WB[(G) < (G0) ? 2 * (G) + 1 : 0] : TW[(G) & 3].hi)
+#define DSS_PGB_HEAD(G0)                                                                         \
+    PairX GX[4];                                                                                 \
+    f32x4 TW[4];                                                                                 \
+    DSS_PGB_LOAD(0, G0)                                                                          \
+    DSS_PGB_LOAD(1, G0)                                                                          \
+    DSS_PGB_LOAD(2, G0)
+#define DSS_PGB_RUN(NBLK, G0)                                                                    \
+    {                                                                                            \
+        DSS_PK_MUL4(GX[0].v[0], GX[0].v[1], GX[0].v[2], GX[0].v[3], DSS_PGB_WLO(0, G0), DSS_PGB_WHI(0, G0)); \
+        _Pragma("unroll") for (int g = 0; g < (NBLK); ++g) {                                     \
+            if (g + 3 < (NBLK)) DSS_PGB_LOAD(g + 3, G0)                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 1 < (NBLK))                                                                  \
+                DSS_PK_STEP4(acc, GX[g & 3].v[0], GX[g & 3].v[1], GX[g & 3].v[2], GX[g & 3].v[3], \
+                             GX[(g + 1) & 3].v[0], GX[(g + 1) & 3].v[1], GX[(g + 1) & 3].v[2], GX[(g + 1) & 3].v[3], \
+                             DSS_PGB_WLO(g + 1, G0), DSS_PGB_WHI(g + 1, G0));                    \
+            else                                                                                 \
+                DSS_PK_ADD4(acc, GX[g & 3].v[0], GX[g & 3].v[1], GX[g & 3].v[2], GX[g & 3].v[3]); \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+
+// wave 7: fold the sampled excitation into the signal history and emit the PCM sample (lpcnet_synthesize_tail_impl);
+// lanes 0..15 carry utterance A, lanes 16..31 utterance B (lanes 32..63 repeat them and store nothing)
+#define DSS_PS_UPDATE()                                                                          \
+    {                                                                                            \
+        float pcm = upd_pred + L.ulaw2lin[upd_exc];                                              \
+        if (TRACE && owner) {                                                                    \
+            const size_t o = ((size_t)my_utt * n_frames + f) * DSS_FRAME_SIZE + upd_i;           \
+            b.trace_exc[o] = (float)upd_exc;                                                     \
+            b.trace_pcm[o] = pcm;                                                                \
+        }                                                                                        \
+        ls_lane = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, pcm),   \
+                                     __builtin_bit_cast(int, ls_lane), 0x111, 0xf, 0xf, false));  \
+        last_exc = upd_exc;                                                                      \
+        pcm += 0.85f * deemph;                                                                   \
+        deemph = pcm;                                                                            \
+        if (pcm < -32767) pcm = -32767;                                                          \
+        if (pcm > 32767) pcm = 32767;                                                            \
+        if (hl == 0 && lane < 32) L.pcm[hb][upd_i] = (short)(int)floor(.5 + (double)pcm);        \
+        upd_pending = false;                                                                     \
+    }
+
+// =====================================================================================================
+// role A: GRU A (+ dual-FC on waves 0..3, + the speculation on waves 0, 1, 5) for the two utterances of the job
+// =====================================================================================================
+template <bool TRACE, bool STAMP, int Z, bool HAS_FC>
+__device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, const DssModelDev &m, const DssBatchDev &b,
+                                                int n_frames, const PairPlan plan, int tid, int wave, int lane)
+{
+    constexpr int HC = DSS_HC;
+    const int unit = m.unit_of[tid];                             // z/r chains + gates of this unit
+    const int uh = m.unit_h[tid];                                // h-gate chain of this (other) unit
+    const int nh = __builtin_amdgcn_readfirstlane(m.wave_nh[wave]);
+    const int nzr = __builtin_amdgcn_readfirstlane(m.wave_nzr[wave]);
+    const char *hw = reinterpret_cast<const char *>(hblk_lds + m.grp_hoff[tid >> 3]) + (lane & 7) * 16;
+    f32x4 WZ[2 * ZRC];                                           // [0,ZRC) z slots, [ZRC,2ZRC) r slots
+    unsigned PZ[(2 * ZRL + 3) / 4], PH[HC / 4];
+#pragma unroll
+    for (int s = 0; s < 2 * ZRC; ++s) {
+        const int slot = s < ZRC ? s : ZRL + (s - ZRC);          // layout numbering
+        WZ[s].x = m.zr_w[((size_t)slot * 4 + 0) * NA + tid];
+        WZ[s].y = m.zr_w[((size_t)slot * 4 + 1) * NA + tid];
+        WZ[s].z = m.zr_w[((size_t)slot * 4 + 2) * NA + tid];
+        WZ[s].w = m.zr_w[((size_t)slot * 4 + 3) * NA + tid];
+    }
+#pragma unroll
+    for (int s = 0; s < (2 * ZRL + 3) / 4; ++s) PZ[s] = m.zr_col[(size_t)s * NA + tid];
+#pragma unroll
+    for (int s = 0; s < HC / 4; ++s) PH[s] = m.h_col[(size_t)s * NA + tid];
+    const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + uh];
+    const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + uh];
+    const f32x2 rbh2 = {rbh, rbh}, dgh2 = {dgh, dgh};
+    // dual-FC constants of tree node `tid` (waves 0..3): fw[j] = (layer 0 weight of input j, layer 1 weight of input j)
+    f32x2 fw[HAS_FC ? NB : 1];
+    float fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
+    if constexpr (HAS_FC) {
+        const int node = tid;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            fw[j].x = m.fc_w[(size_t)node * 2 * NB + j];
+            fw[j].y = m.fc_w[(size_t)node * 2 * NB + NB + j];
+        }
+        fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
+        ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
+    }
+    const float u2l_c = L.ulaw2lin[(HAS_FC ? 128 + tid : tid - 256) & 255];   // this lane's excitation candidate (waves 0, 1, 5)
+    const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
+    const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;     // wave-uniform (kernel argument)
+    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
+
+    for (int jn = 0; jn < plan.n_jobs; ++jn) {
+        const PairJob job = dss_pair_job(plan, jn);
+        const int ua = job.ua, ub = job.ub, fc0 = job.fc0;
+        dss_pair_job_init(L, b, job, tid);
+        __syncthreads();                                             // job barrier 0: decoder state in LDS
+        int cur = 0;
+        f32x2 st = *reinterpret_cast<const f32x2 *>(&L.state_a[0][2 * unit]);
+        bool first_sample = true;
+        DSS_PH_CHAIN(L.state_a[0])                                   // first sample of this call
+        __syncthreads();                                             // job barrier 1: L.ah of every unit visible to its z/r lane
+
+        for (int f = 0; f < n_frames; ++f) {
+            if (fc0 + f < DSS_FEATURES_DELAY) continue;              // silent frame: decoder state untouched
+            const float *foa = b.frame_out + ((size_t)ua * n_frames + f) * DSS_COND_STRIDE;     // wave-uniform bases
+            const float *fob = b.frame_out + ((size_t)ub * n_frames + f) * DSS_COND_STRIDE;
+            const f32x2 cz = {foa[(unsigned)unit], fob[(unsigned)unit]};
+            const f32x2 cr = {foa[(unsigned)(NA + unit)], fob[(unsigned)(NA + unit)]};
+            const f32x2 ch = {foa[(unsigned)(2 * NA + unit)], fob[(unsigned)(2 * NA + unit)]};
+            for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+                // keep the packed column ids opaque so the per-slot unpacking is not hoisted out of the sample loop
+#pragma unroll
+                for (int k = 0; k < (2 * ZRL + 3) / 4; ++k) asm volatile("" : "+v"(PZ[k]));
+#pragma unroll
+                for (int k = 0; k < HC / 4; ++k) asm volatile("" : "+v"(PH[k]));
+                f32x2 az = rbz + dgz * st;                           // compute_sparse_gru, before the input term
+                f32x2 ar = rbr + dgr * st;
+                const f32x2 ahv = *reinterpret_cast<const f32x2 *>(&L.ah[unit][0]);   // h-gate pre-activation (its h lane, B..C)
+                // The three embedding indices of either utterance.  First sample of a call: wave 7 computes them (L.idx,
+                // barrier A).  Every later sample: this wave walks both sampling trees itself and looks the speculated
+                // indices up.
+                int sia, pia, eia, sib, pib, eib;
+                if (first_sample) {
+                    __syncthreads();                                                    // barrier A (first sample only)
+                    sia = L.idx[0][0]; pia = L.idx[0][1]; eia = L.idx[0][2];
+                    sib = L.idx[1][0]; pib = L.idx[1][1]; eib = L.idx[1][2];
+                    first_sample = false;
+                } else {
+                    int ea_, eb_;
+                    DSS_TREE_WALK_AT(ea_, L.bits[0])
+                    DSS_TREE_WALK_AT(eb_, L.bits[1])
+                    const unsigned xa = __builtin_amdgcn_readfirstlane((unsigned)L.spec_tab_idx[0][ea_]);
+                    const unsigned xb_ = __builtin_amdgcn_readfirstlane((unsigned)L.spec_tab_idx[1][eb_]);
+                    sia = (int)(xa & 0xFF); pia = (int)(xa >> 8); eia = ea_;
+                    sib = (int)(xb_ & 0xFF); pib = (int)(xb_ >> 8); eib = eb_;
+                }
+                sia = __builtin_amdgcn_readfirstlane(sia); pia = __builtin_amdgcn_readfirstlane(pia); eia = __builtin_amdgcn_readfirstlane(eia);
+                sib = __builtin_amdgcn_readfirstlane(sib); pib = __builtin_amdgcn_readfirstlane(pib); eib = __builtin_amdgcn_readfirstlane(eib);
+                if (STAMP) ta = __builtin_readcyclecounter();
+                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                const f32x3 esa = *reinterpret_cast<const f32x3 *>(m.embed_lane[0] + ((unsigned)sia * NA + (unsigned)tid) * 3);
+                const f32x3 epa = *reinterpret_cast<const f32x3 *>(m.embed_lane[1] + ((unsigned)pia * NA + (unsigned)tid) * 3);
+                const f32x3 eea = *reinterpret_cast<const f32x3 *>(m.embed_lane[2] + ((unsigned)eia * NA + (unsigned)tid) * 3);
+                const f32x3 esb = *reinterpret_cast<const f32x3 *>(m.embed_lane[0] + ((unsigned)sib * NA + (unsigned)tid) * 3);
+                const f32x3 epb = *reinterpret_cast<const f32x3 *>(m.embed_lane[1] + ((unsigned)pib * NA + (unsigned)tid) * 3);
+                const f32x3 eeb = *reinterpret_cast<const f32x3 *>(m.embed_lane[2] + ((unsigned)eib * NA + (unsigned)tid) * 3);
+                // first z/r block's state pairs: independent of the embedding rows, fetched under their latency
+                const char *xb = reinterpret_cast<const char *>(L.state_a[cur]);
+                PairX XZ[2], XR[2];
+                dss_pair_loadx(XZ[0], xb + DSS_ZR_COL(0) * 32);
+                dss_pair_loadx(XR[0], xb + DSS_ZR_COL(ZRL) * 32);
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[0] += t - ta; ta = t; }
+                f32x2 gz, gr, gh;                                                     // compute_gru_a_input
+                gz.x = ((cz.x + esa.x) + epa.x) + eea.x;  gz.y = ((cz.y + esb.x) + epb.x) + eeb.x;
+                gr.x = ((cr.x + esa.y) + epa.y) + eea.y;  gr.y = ((cr.y + esb.y) + epb.y) + eeb.y;
+                gh.x = ((ch.x + esa.z) + epa.z) + eea.z;  gh.y = ((ch.y + esb.z) + epb.z) + eeb.z;
+                // nnet.c 2021 (default): (bias + diag*state) + input, then the blocks in idx order;
+                // nnet.c 2019-20 (blob flag): the blocks first, the input last
+                if (!recur_first) { az = az + gz; ar = ar + gr; }
+                if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[1] += t - ta; ta = t; }
+#pragma unroll
+                for (int s = 0; s < ZRC; s += 2) {
+                    if (s < nzr) {                                   // nzr is even: slots s and s+1 exist
+                        dss_pair_loadx(XZ[1], xb + DSS_ZR_COL(s + 1) * 32);
+                        dss_pair_loadx(XR[1], xb + DSS_ZR_COL(ZRL + s + 1) * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                        DSS_PK_ZR4(az, ar, XZ[0].v[0], XZ[0].v[1], XZ[0].v[2], XZ[0].v[3], XR[0].v[0], XR[0].v[1], XR[0].v[2], XR[0].v[3],
+                                   WZ[s].lo, WZ[s].hi, WZ[ZRC + s].lo, WZ[ZRC + s].hi);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s + 2 < ZRC && s + 2 < nzr) {
+                            dss_pair_loadx(XZ[0], xb + DSS_ZR_COL(s + 2 < ZRC ? s + 2 : 0) * 32);
+                            dss_pair_loadx(XR[0], xb + DSS_ZR_COL(ZRL + (s + 2 < ZRC ? s + 2 : 0)) * 32);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        DSS_PK_ZR4(az, ar, XZ[1].v[0], XZ[1].v[1], XZ[1].v[2], XZ[1].v[3], XR[1].v[0], XR[1].v[1], XR[1].v[2], XR[1].v[3],
+                                   WZ[s + 1].lo, WZ[s + 1].hi, WZ[ZRC + s + 1].lo, WZ[ZRC + s + 1].hi);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (recur_first) { az = gz + az; ar = gr + ar; }
+                if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
+                const f32x2 z = dss_sigmoid_pk(L.tansig, az), r = dss_sigmoid_pk(L.tansig, ar);
+                f32x2 h = ahv * r + gh;
+                h = dss_tanh_pk(L.tansig, h);
+                st = z * st + (1 - z) * h;
+                *reinterpret_cast<f32x2 *>(&L.state_a[cur ^ 1][2 * unit]) = st;
+                if (STAMP) { asm volatile("" :: "v"(st)); unsigned long long t = __builtin_readcyclecounter(); sa[3] += t - ta; ta = t; }
+                __syncthreads();                                                        // barrier B
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
+                DSS_PH_CHAIN(L.state_a[cur ^ 1])                     // next sample's h chain, under GRU B
+                if (wave == 5 || wave < 2)                           // candidates 64..127 (wave 5), 128..255 (waves 0, 1); wave 6: 0..63
+                    dss_pair_speculate(L, HAS_FC ? 128 + tid : tid - 256, u2l_c);
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
+                __syncthreads();                                                        // barrier C
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
+                if constexpr (HAS_FC) {                                                 // sample_mdense, all nodes, both utterances
+                    const float thr_a = L.thr[0][level], thr_b = L.thr[1][level];      // issued first, used last
+                    f32x2 s0 = {fb0, fb0}, s1 = {fb1, fb1};                            // layer 0 / layer 1 sums of (A, B)
+#pragma unroll
+                    for (int j4 = 0; j4 < NB / 4; ++j4) {
+                        PairX bj;
+                        dss_pair_loadx(bj, reinterpret_cast<const char *>(&L.state_b[4 * j4][0]));
+                        f32x2 t0, t1, t2, t3;
+                        DSS_PK_FC4(s0, s1, t0, t1, t2, t3, bj.v[0], bj.v[1], bj.v[2], bj.v[3],
+                                   fw[4 * j4], fw[4 * j4 + 1], fw[4 * j4 + 2], fw[4 * j4 + 3]);
+                    }
+                    const f32x2 t1 = dss_tanh_pk(L.tansig, s0), t2 = dss_tanh_pk(L.tansig, s1);
+                    f32x2 lg = ff0 * t1;
+                    const f32x2 lg2 = ff1 * t2;
+                    lg += lg2;
+                    bool bit_a = thr_a < lg.x, bit_b = thr_b < lg.y;
+                    if constexpr (TRACE) {               // teacher forcing (tests): record every logit, bend the walk
+                        const size_t oa = ((size_t)ua * n_frames + f) * DSS_FRAME_SIZE + i;
+                        const size_t ob = ((size_t)ub * n_frames + f) * DSS_FRAME_SIZE + i;
+                        if (b.trace_logits) {
+                            b.trace_logits[oa * 256 + tid] = tid ? lg.x : 0.f;
+                            if (job.has_b) b.trace_logits[ob * 256 + tid] = tid ? lg.y : 0.f;
+                        }
+                        if (b.force_exc) {
+                            const int va = b.force_exc[oa], vb = b.force_exc[ob];       // bits b7..b0, b7 decided at level 0
+                            if ((tid ^ (1 << level)) == (va >> (8 - level))) bit_a = (va >> (7 - level)) & 1;
+                            if ((tid ^ (1 << level)) == (vb >> (8 - level))) bit_b = (vb >> (7 - level)) & 1;
+                        }
+                    }
+                    const unsigned long long mask_a = __ballot(bit_a), mask_b = __ballot(bit_b);
+                    if (lane == 0) {
+                        L.bits[0][2 * wave] = (unsigned)mask_a; L.bits[0][2 * wave + 1] = (unsigned)(mask_a >> 32);
+                        L.bits[1][2 * wave] = (unsigned)mask_b; L.bits[1][2 * wave + 1] = (unsigned)(mask_b >> 32);
+                    }
+                }
+                __syncthreads();                                                        // barrier D
+                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[7] += t - ta; ta = t; }
+                cur ^= 1;
+            }
+        }
+        __syncthreads();                                                                // final barrier of the job
+        b.gru_a_state[(size_t)ua * NA + unit] = st.x;
+        if (job.has_b) b.gru_a_state[(size_t)ub * NA + unit] = st.y;
+        __syncthreads();                                                                // job barrier 2: LDS free for the next job
+    }
+    if (STAMP && lane == 0 && b.trace_exc)
+        for (int k = 0; k < 8; ++k) b.trace_exc[((size_t)(plan.u0 >> 1) * 6 + wave) * 8 + k] = (float)sa[k];
+}
+
+template <bool TRACE, bool STAMP, int Z>
+__global__ void __launch_bounds__(512)
+lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames, short *__restrict__ pcm_out)
+{
+    __shared__ __attribute__((aligned(16))) PairLds L;
+    extern __shared__ __attribute__((aligned(16))) float hblk_lds[];       // h-gate block records (size per model)
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    PairPlan plan;
+    {
+        const int u0 = 2 * blockIdx.x, u1 = u0 + 1;
+        const bool has1 = u1 < n_utts;
+        const int fa = b.fc0[u0], fb = has1 ? b.fc0[u1] : fa;
+        const bool same = min(fa, DSS_FEATURES_DELAY) == min(fb, DSS_FEATURES_DELAY);
+        plan.u0 = u0; plan.fa = __builtin_amdgcn_readfirstlane(fa); plan.fb = __builtin_amdgcn_readfirstlane(fb);
+        plan.packed = has1 && same;
+        plan.n_jobs = (has1 && !same) ? 2 : 1;
+    }
+
+    // ---------------- one-time staging into LDS -------------------------------------------------------
+    for (int k = tid * 4; k < m.hblk_floats; k += 512 * 4)
+        *reinterpret_cast<f32x4 *>(&hblk_lds[k]) = *reinterpret_cast<const f32x4 *>(&m.hblk[k]);
+    for (int k = tid; k < NB * NB3; k += 512) L.gb_wrec[k] = m.gru_b_w_rec[k];
+    for (int k = tid; k < NB3 * PGBL; k += 512) {
+        const int row = k / PGBL, j = k - row * PGBL;
+        L.gb_wl[row * PGL_STRIDE + j] = m.gb_w_lane[(size_t)(PGB6 + PGB7 + j) * 64 + row];
+    }
+    if (tid < 201) L.tansig[tid] = m.tansig[tid];
+    if (tid < 256) L.ulaw2lin[tid] = m.ulaw2lin[tid];
+    __syncthreads();
+
+    if (wave < 4) {
+        dss_pair_role_a<TRACE, STAMP, (Z < 8 ? Z : 8), true>(L, hblk_lds, m, b, n_frames, plan, tid, wave, lane);
+    } else if (wave < 6) {
+        dss_pair_role_a<TRACE, STAMP, Z, false>(L, hblk_lds, m, b, n_frames, plan, tid, wave, lane);
+    } else if (wave == 6) {
+        // =====================================================================================================
+        // role B1: GRU B over inputs 0..PGB6-1, lane = row (0..15 z, 16..31 r, 32..47 h), both utterances per lane
+        // =====================================================================================================
+        f32x2 WB[PGB6 / 2];
+#pragma unroll
+        for (int j = 0; j < PGB6 / 2; ++j) {
+            WB[j].x = m.gb_w_lane[(size_t)(2 * j) * 64 + lane];
+            WB[j].y = m.gb_w_lane[(size_t)(2 * j + 1) * 64 + lane];
+        }
+        const int row = lane < NB3 ? lane : 0;
+        __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
+        const float gbb0 = m.gru_b_bias[row];
+        const float u2l_c = L.ulaw2lin[lane];
+        for (int jn = 0; jn < plan.n_jobs; ++jn) {
+            const PairJob job = dss_pair_job(plan, jn);
+            dss_pair_job_init(L, b, job, tid);
+            __syncthreads();                                             // job barrier 0
+            int cur = 0, seq = 0;
+            __syncthreads();                                             // job barrier 1
+            for (int f = 0; f < n_frames; ++f) {
+                if (job.fc0 + f < DSS_FEATURES_DELAY) continue;
+                const f32x2 gbc = {b.frame_out[((size_t)job.ua * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row],
+                                   b.frame_out[((size_t)job.ub * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row]};
+                for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+                    f32x2 acc = gbb0 + gbc;                                                 // compute_gruB
+                    ++seq;
+                    if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
+                    __syncthreads();                                                        // barrier B
+                    const char *an = reinterpret_cast<const char *>(L.state_a[cur ^ 1]);
+                    const char *wl = nullptr;                        // (no LDS-resident weights in this wave's part)
+                    DSS_PGB_HEAD(PGB6 / 4)
+                    DSS_PGB_RUN(PGB6 / 4, PGB6 / 4)
+                    *reinterpret_cast<f32x2 *>(&L.gb_acc[lane][0]) = acc;
+                    __hip_atomic_store(&L.gb_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    dss_pair_speculate(L, lane, u2l_c);          // this wave is idle from here to barrier B: candidates 0..63
+                    __syncthreads();                                                        // barrier C
+                    __syncthreads();                                                        // barrier D
+                    cur ^= 1;
+                }
+            }
+            __syncthreads();                                                                // final barrier of the job
+            __syncthreads();                                                                // job barrier 2
+        }
+    } else {
+        // =====================================================================================================
+        // role B2 + S (wave 7): GRU B inputs PGB6..383 and gates (both utterances per lane); scalar recurrences with
+        // utterance A in lanes 0..15 and utterance B in lanes 16..31
+        // =====================================================================================================
+        f32x2 WB[PGB7 / 2];
+#pragma unroll
+        for (int j = 0; j < PGB7 / 2; ++j) {
+            WB[j].x = m.gb_w_lane[(size_t)(PGB6 + 2 * j) * 64 + lane];
+            WB[j].y = m.gb_w_lane[(size_t)(PGB6 + 2 * j + 1) * 64 + lane];
+        }
+        const int row = lane < NB3 ? lane : 0;
+        __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
+        const float gbb1 = m.gru_b_bias[NB3 + row];
+        const int hb = (lane >> 4) & 1, hl = lane & (DSS_LPC_ORDER - 1);
+        unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long t_prev = 0;
+        for (int jn = 0; jn < plan.n_jobs; ++jn) {
+            const PairJob job = dss_pair_job(plan, jn);
+            const int my_utt = hb ? job.ub : job.ua;                 // uniform calls: row == decoder slot
+            const bool owner = hl == 0 && lane < 32 && (hb == 0 || job.has_b);   // the lane that stores its utterance's scalars
+            dss_pair_job_init(L, b, job, tid);
+            __syncthreads();                                             // job barrier 0
+            // signal history and LPC of the current frame, element j of utterance hb in lane 16*hb + j
+            float ls_lane = b.last_sig[(size_t)my_utt * DSS_LPC_ORDER + hl], lpc_lane = 0.f;
+            float deemph = b.deemph[my_utt];
+            int last_exc = b.last_exc[my_utt];
+            DssKiss99 rng = {b.rng[my_utt * 4 + 0], b.rng[my_utt * 4 + 1], b.rng[my_utt * 4 + 2], b.rng[my_utt * 4 + 3]};
+            int cur = 0, seq = 0;
+            float pred = 0.f, upd_pred = 0.f;
+            int upd_exc = 0, upd_i = 0;
+            bool have_spec = false, next_exists = false, upd_pending = false;
+            __syncthreads();                                             // job barrier 1
+            for (int f = 0; f < n_frames; ++f) {
+                short *pcm_a = pcm_out + ((size_t)job.ua * n_frames + f) * DSS_FRAME_SIZE;
+                short *pcm_b = pcm_out + ((size_t)job.ub * n_frames + f) * DSS_FRAME_SIZE;
+                if (job.fc0 + f < DSS_FEATURES_DELAY) {             // lpcnet.c: frame_count <= FEATURES_DELAY -> silence
+                    for (int k = lane; k < DSS_FRAME_SIZE / 2; k += 64) {
+                        reinterpret_cast<int *>(pcm_a)[k] = 0;
+                        if (job.has_b) reinterpret_cast<int *>(pcm_b)[k] = 0;
+                    }
+                    if (TRACE)
+                        for (int k = lane; k < DSS_FRAME_SIZE; k += 64) {
+                            b.trace_exc[((size_t)job.ua * n_frames + f) * DSS_FRAME_SIZE + k] = -1.f;
+                            b.trace_pcm[((size_t)job.ua * n_frames + f) * DSS_FRAME_SIZE + k] = 0.f;
+                            if (job.has_b) {
+                                b.trace_exc[((size_t)job.ub * n_frames + f) * DSS_FRAME_SIZE + k] = -1.f;
+                                b.trace_pcm[((size_t)job.ub * n_frames + f) * DSS_FRAME_SIZE + k] = 0.f;
+                            }
+                        }
+                    continue;
+                }
+                const float *fo = b.frame_out + ((size_t)my_utt * n_frames + f) * DSS_COND_STRIDE;
+                lpc_lane = fo[3 * NA + NB3 + hl];
+                for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+                    if (STAMP) t_prev = __builtin_readcyclecounter();
+                    if (!have_spec) {        // first sample of the call: prediction and indices computed directly
+                        pred = 0;
+#pragma unroll
+                        for (int j = 0; j < DSS_LPC_ORDER; ++j) {
+                            const int src = ((lane & 0x30) | j) * 4;
+                            pred -= __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ls_lane))) *
+                                    __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, lpc_lane)));
+                        }
+                        const int su = dss_lin2ulaw(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane & 0x30) * 4, __builtin_bit_cast(int, ls_lane))));
+                        const int pu = dss_lin2ulaw(pred);
+                        if (hl == 0 && lane < 32) { L.idx[hb][0] = su; L.idx[hb][1] = pu; L.idx[hb][2] = last_exc; }
+                    }
+                    ++seq;
+                    if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[0] += t - t_prev; t_prev = t; }
+                    if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
+                    if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[1] += t - t_prev; t_prev = t; }
+                    if (upd_pending) { DSS_PS_UPDATE() }                                    // previous sample's bookkeeping
+                    {   // off the critical path: this sample's 8 thresholds per utterance
+                        const uint32_t r0 = dss_kiss99_rand(rng);
+                        const uint32_t r1 = dss_kiss99_rand(rng);
+                        if (hl < 8 && lane < 32) {
+                            const uint32_t r = hl < 4 ? r0 : r1;
+                            L.thr[hb][hl] = m.logit_table[(r >> (8 * (hl & 3))) & 0xFF];     // 1 KB table, L2/L1 resident
+                        }
+                    }
+                    {   // inputs of the speculation the other waves run between barriers B and C
+                        const bool last_of_frame = (i == DSS_FRAME_SIZE - 1);
+                        next_exists = !(last_of_frame && f == n_frames - 1);
+                        float lp = lpc_lane;
+                        if (last_of_frame && next_exists)
+                            lp = b.frame_out[((size_t)my_utt * n_frames + f + 1) * DSS_COND_STRIDE + 3 * NA + NB3 + hl];
+                        // history[j-1] arrives in lane j (row_shr:1 inside each row of 16 lanes)
+                        const float ls_up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ls_lane), 0x111, 0xf, 0xf, false));
+                        const float prod = ls_up * lp;
+                        if (lane < 32) L.spec_prod[hl][hb] = hl ? prod : lp;
+                        if (hl == 0 && lane < 32) L.spec_pred[hb] = pred;
+                    }
+                    f32x2 rec = {gbb1, gbb1};                                               // GRU B's recurrent half
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) rec += L.gb_wrec[j * NB3 + row] * *reinterpret_cast<const f32x2 *>(&L.state_b[j][0]);
+                    const f32x2 sb_old = *reinterpret_cast<const f32x2 *>(&L.state_b[lane & (NB - 1)][0]);   // the h lanes' own unit
+                    __syncthreads();                                                        // barrier B
+                    if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[2] += t - t_prev; t_prev = t; }
+                    const char *an = reinterpret_cast<const char *>(L.state_a[cur ^ 1]) + PGB6 * 8;
+                    const char *wl = reinterpret_cast<const char *>(L.gb_wl + row * PGL_STRIDE);
+                    DSS_PGB_HEAD(PGB7 / 4)                           // the first state pairs of its part, under the wait
+                    __builtin_amdgcn_sched_barrier(0);
+                    while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
+                        ;                                    // tight poll: one LDS round trip per iteration is pause enough
+                    f32x2 acc = *reinterpret_cast<const f32x2 *>(&L.gb_acc[lane][0]);
+                    DSS_PGB_RUN((PGB7 + PGBL) / 4, PGB7 / 4)
+                    {   // gates: lanes 0..15 z, 16..31 r, 32..47 h.  r and z travel up to their unit's h lane with gfx950's
+                        // row/half swaps (VALU); the new state is formed in the h lanes.  Only the first result of a swap
+                        // is used, with distinct operands (see lpcnet_sample.hip).
+                        const f32x2 zr = dss_sigmoid_pk(L.tansig, acc + rec);
+                        f32x2 r_for_h, z_for_h;
+                        {
+                            const float zrx = zr.x;           // (a bit cast applied to a vector ELEMENT reads element 0 with this clang)
+                            const unsigned zb = __builtin_bit_cast(unsigned, zrx);
+                            const unsigned r_row0 = __builtin_amdgcn_permlane16_swap(zb, 0u, false, false)[1];
+                            r_for_h.x = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(0u, r_row0, false, false)[0]);
+                            z_for_h.x = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(0u, zb, false, false)[0]);
+                        }
+                        {
+                            const float zry = zr.y;
+                            const unsigned zb = __builtin_bit_cast(unsigned, zry);
+                            const unsigned r_row0 = __builtin_amdgcn_permlane16_swap(zb, 0u, false, false)[1];
+                            r_for_h.y = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(0u, r_row0, false, false)[0]);
+                            z_for_h.y = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(0u, zb, false, false)[0]);
+                        }
+                        f32x2 hh = acc + rec * r_for_h;
+                        hh = dss_tanh_pk(L.tansig, hh);
+                        if (lane >= 2 * NB && lane < NB3)
+                            *reinterpret_cast<f32x2 *>(&L.state_b[lane - 2 * NB][0]) = z_for_h * sb_old + (1 - z_for_h) * hh;
+                    }
+                    __syncthreads();                                                        // barrier C
+                    if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
+                    __syncthreads();                                                        // barrier D
+                    if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[4] += t - t_prev; t_prev = t; }
+                    cur ^= 1;
+                    int va, vb;
+                    DSS_TREE_WALK_AT(va, L.bits[0])
+                    DSS_TREE_WALK_AT(vb, L.bits[1])
+                    const int exc = hb ? vb : va;
+                    // the next sample's prediction and mu-law indices were precomputed for every possible exc
+                    const float pred_next = L.spec_tab_pred[hb][exc];   // (the GRU A waves look the mu-law indices up themselves)
+                    have_spec = next_exists;
+                    // Everything below only updates this wave's own state; except at the end of a frame (whose PCM is
+                    // copied out right after the loop) it is deferred until after the next barrier A.
+                    upd_exc = exc; upd_pred = pred; upd_i = i; upd_pending = true;
+                    pred = pred_next;
+                    if (i == DSS_FRAME_SIZE - 1) { DSS_PS_UPDATE() }
+                    if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[5] += t - t_prev; t_prev = t; }
+                }
+                // wave 7 owns L.pcm: LDS operations of one wave are ordered, no barrier needed
+                for (int k = lane; k < DSS_FRAME_SIZE / 2; k += 64) {
+                    reinterpret_cast<int *>(pcm_a)[k] = reinterpret_cast<const int *>(L.pcm[0])[k];
+                    if (job.has_b) reinterpret_cast<int *>(pcm_b)[k] = reinterpret_cast<const int *>(L.pcm[1])[k];
+                }
+            }
+            __syncthreads();                                                                // final barrier of the job
+            if (lane < NB) {
+                b.gru_b_state[(size_t)job.ua * NB + lane] = L.state_b[lane][0];
+                if (job.has_b) b.gru_b_state[(size_t)job.ub * NB + lane] = L.state_b[lane][1];
+            }
+            if (lane < 32 && (hb == 0 || job.has_b)) b.last_sig[(size_t)my_utt * DSS_LPC_ORDER + hl] = ls_lane;
+            if (owner) {
+                b.deemph[my_utt] = deemph;
+                b.last_exc[my_utt] = last_exc;
+                b.rng[my_utt * 4 + 0] = rng.z; b.rng[my_utt * 4 + 1] = rng.w; b.rng[my_utt * 4 + 2] = rng.jsr; b.rng[my_utt * 4 + 3] = rng.jcong;
+            }
+            __syncthreads();                                                                // job barrier 2
+        }
+        if (STAMP && lane == 0 && b.trace_pcm)          // diagnostic build only
+            for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)(plan.u0 >> 1) * 6 + k] = (float)stamp_acc[k];
+    }
+}
+
+// 1 when the CU-resident layout of model m also fits beside two utterances' state (plain layouts only: models that
+// need the z/r tail or long-list paths stay on the latency kernel)
+int dss_pair_fits(const DssModelDev &m)
+{
+    return m.fast_ok && !m.ext && (size_t)m.hblk_floats * sizeof(float) <= DSS_PAIR_HBLK_BYTES;
+}
+
+// uniform calls only (row i continues decoder slot i, every row has n_frames frames); trace: 0, 1 (excitation / pcm trace
+// and teacher forcing), 2 (phase stamps of the diagnostic build)
+int dss_launch_sample_network_pair(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm, int trace,
+                                   hipStream_t s)
+{
+    if (!dss_pair_fits(m) || b.slot_of || b.count_of) { dss_set_error("pair kernel: model or call shape not supported"); return DSS_EINVAL; }
+    const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
+    const bool z10 = m.zr_cap <= 10;
+    static std::mutex attr_mu;
+    static unsigned long long attr_set = 0;
+    int dev = 0;
+    DSS_HIP_CHECK(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> attr_lk(attr_mu);
+        if (!(attr_set >> (dev & 63) & 1)) {
+#define DSS_SET_ATTR(K) DSS_HIP_CHECK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_PAIR_HBLK_BYTES))
+            DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, false, 10>)); DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, false, 12>));
+            DSS_SET_ATTR((lpcnet_sample_pair_kernel<true, false, 10>));  DSS_SET_ATTR((lpcnet_sample_pair_kernel<true, false, 12>));
+            DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, true, 10>));  DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, true, 12>));
+#undef DSS_SET_ATTR
+            attr_set |= 1ull << (dev & 63);
+        }
+    }
+    const dim3 grid((n_utts + 1) / 2), block(512);
+#define DSS_LAUNCH(T, S2)                                                                                              \
+    do {                                                                                                               \
+        if (z10) hipLaunchKernelGGL((lpcnet_sample_pair_kernel<T, S2, 10>), grid, block, dyn, s, m, b, n_utts, n_frames, d_pcm); \
+        else hipLaunchKernelGGL((lpcnet_sample_pair_kernel<T, S2, 12>), grid, block, dyn, s, m, b, n_utts, n_frames, d_pcm);     \
+    } while (0)
+    if (trace == 2) DSS_LAUNCH(false, true);
+    else if (trace) DSS_LAUNCH(true, false);
+    else DSS_LAUNCH(false, false);
+#undef DSS_LAUNCH
+    DSS_HIP_CHECK(hipGetLastError());
+    return DSS_OK;
+}

@@ -211,7 +211,8 @@ class LPCNetBatch:
         _lib.check(self._L.dss_lpcnet_batch_force_excitation(self._h, e.ctypes.data, e.shape[0], int(n_frames)))
 
     def set_multi(self, utterances_per_workgroup: int = 0):
-        """0 = automatic, -1 = latency kernel only, 3 / 4 = force the throughput kernel (dss_lpcnet_batch_set_multi)."""
+        """Utterances per workgroup: 0 = automatic (two once the call has more utterances than the chip has CUs), 1 or -1 =
+        always one (latency kernel), 2 = always two (packed-pair kernel); dss_lpcnet_batch_set_multi."""
         _lib.check(self._L.dss_lpcnet_batch_set_multi(self._h, int(utterances_per_workgroup)))
 
     def enable_timing(self, on=True):

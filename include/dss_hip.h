@@ -138,10 +138,12 @@ int dss_lpcnet_batch_synthesize_ragged_dev(dss_lpcnet_batch *b, const float *d_f
                                            short *d_pcm, void *hip_stream);
 int dss_lpcnet_batch_synthesize_ragged(dss_lpcnet_batch *b, const float *features, const int *slots,
                                        const int *counts, int n_utts, int n_frames, int feat_stride, short *pcm);
-/* Kernel choice for uniform calls (no slots / counts, no trace).  0 (default): the latency kernel (one utterance per
- * workgroup) up to one utterance per CU, the throughput kernel (3 or 4 utterances software-pipelined through one
- * workgroup, csrc/lpcnet_sample_multi.hip) beyond; -1: always the latency kernel; 3 / 4: force that many per workgroup.
- * Results are bit-identical either way. */
+/* Kernel choice for uniform calls (no slots / counts).  0 (default): one utterance per workgroup (csrc/lpcnet_sample.hip)
+ * while the call has at most one utterance per CU, two utterances per workgroup -- carried as the two halves of packed
+ * fp32 instructions, csrc/lpcnet_sample_pair.hip -- beyond; 1 or -1: always one per workgroup; 2: always two (fails with
+ * DSS_EINVAL for a model whose CU-resident layout leaves no room for the second utterance).  Ragged calls and models on
+ * the extended / generic paths always run one utterance per workgroup.  Results are bit-identical either way, and a
+ * decoder state written by one form is continued by the other. */
 int dss_lpcnet_batch_set_multi(dss_lpcnet_batch *b, int utterances_per_workgroup);
 /* Test taps (device -> host): frame-rate network outputs of the LAST call, per utterance and frame:
  * which = 0: gru_a_condition [n_frames][3*gru_a]; 1: gru_b_condition [n_frames][3*gru_b]; 2: lpc [n_frames][16].

@@ -450,51 +450,98 @@ def test_void_synthesize_never_aborts(model):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# throughput kernel: 3 or 4 utterances software-pipelined through one workgroup (csrc/lpcnet_sample_multi.hip)
+# throughput kernel: two utterances per workgroup as the halves of packed fp32 instructions (csrc/lpcnet_sample_pair.hip)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("U", [3, 4])
-def test_multi_utterance_kernel_bit_exact(oracle, model, U):
-    """Forced on small batches, including workgroups that are only partly filled (7 and 10 are not multiples of 3 / 4),
-    a one-frame call, and state carried over several calls (the second call starts with frame_count > 0, so its first
-    frames are NOT silent and every utterance record is initialised from the saved decoder state)."""
+def test_pair_kernel_bit_exact(oracle, model):
+    """Forced on small batches: even and odd utterance counts (the last workgroup of an odd call carries one utterance),
+    a single utterance, a one-frame call, and state carried over several calls (the later calls start with
+    frame_count > 0, so their first frames are NOT silent)."""
     from dss_amd.lpcnet import LPCNetBatch
-    for B, F in ((7, 6), (10, 3), (1, 4)):
+    for B, F in ((6, 6), (7, 5), (1, 4), (3, 1)):
         feats = np.stack([synthetic_features(1200 + b, F) for b in range(B)])
         gpu = LPCNetBatch(B, F)
-        gpu.set_multi(U)
+        gpu.set_multi(2)
         pcm = gpu.synthesize(feats)
         for b in range(B):
-            assert np.array_equal(pcm[b], oracle.lpcnet_utterance(model, feats[b])), (U, B, F, b)
+            assert np.array_equal(pcm[b], oracle.lpcnet_utterance(model, feats[b])), (B, F, b)
     # chunked: 1, 1, 1, 2, 5 frames through one batch object vs one oracle decoder per utterance
     B, F = 5, 10
     feats = np.stack([synthetic_features(1300 + b, F) for b in range(B)])
     gpu = LPCNetBatch(B, 5)
-    gpu.set_multi(U)
+    gpu.set_multi(2)
     decs = [oracle.decoder(model) for _ in range(B)]
     t = 0
     for n in (1, 1, 1, 2, 5):
         got = gpu.synthesize(feats[:, t:t + n])
         for b in range(B):
             want = np.concatenate([decs[b].synthesize(feats[b, t + q]) for q in range(n)])
-            assert np.array_equal(got[b], want), (U, t, n, b)
+            assert np.array_equal(got[b], want), (t, n, b)
         t += n
-    # and the latency kernel continues a state the throughput kernel left (and vice versa)
-    gpu.set_multi(-1)
-    more = synthetic_features(1400, 2)
-    got = gpu.synthesize(np.stack([more] * B))
-    for b in range(B):
-        want = np.concatenate([decs[b].synthesize(more[q]) for q in range(2)])
-        assert np.array_equal(got[b], want), (U, "latency kernel after throughput kernel", b)
-    gpu.set_multi(U)
-    got = gpu.synthesize(np.stack([more] * B))
-    for b in range(B):
-        want = np.concatenate([decs[b].synthesize(more[q]) for q in range(2)])
-        assert np.array_equal(got[b], want), (U, "throughput kernel after latency kernel", b)
+    # the latency kernel continues a state the pair kernel left, and the other way round
+    more = synthetic_features(1400, 4)
+    for mode, rows in ((1, slice(0, 2)), (2, slice(2, 4))):
+        gpu.set_multi(mode)
+        got = gpu.synthesize(np.stack([more[rows]] * B))
+        for b in range(B):
+            want = np.concatenate([decs[b].synthesize(more[q]) for q in range(rows.start, rows.stop)])
+            assert np.array_equal(got[b], want), ("hand-over", mode, b)
 
 
-def test_multi_utterance_kernel_other_models(oracle):
-    """Recurrent-first association order and a model at the 12-slot z/r capacity, through the throughput kernel."""
-    from dss_amd import lpcnet
+def test_pair_kernel_unequal_silence_and_trace(oracle, model):
+    """Two utterances of one workgroup whose decoders are at different points of the two-frame look-ahead (one fresh, one
+    continued) cannot share the silent-frame schedule: the workgroup runs them one after the other.  Then the traced
+    instantiation: sampled excitation, pre-quantised value, and teacher-forced logits of all 255 nodes for both
+    utterances of a workgroup."""
+    from dss_amd.lpcnet import LPCNetBatch
+    B, F = 4, 5
+    feats = np.stack([synthetic_features(1600 + b, 2 * F) for b in range(B)])
+    gpu = LPCNetBatch(B, F)
+    gpu.set_multi(2)
+    decs = [oracle.decoder(model) for _ in range(B)]
+    first = gpu.synthesize(feats[:, :F])
+    for b in range(B):
+        assert np.array_equal(first[b], np.concatenate([decs[b].synthesize(feats[b, t]) for t in range(F)])), b
+    gpu.reset(1)                                         # utterances 0 and 1 share a workgroup; 1 starts over, 0 goes on
+    gpu.reset(2)
+    decs[1].reset()
+    decs[2].reset()
+    second = gpu.synthesize(feats[:, F:])
+    for b in range(B):
+        want = np.concatenate([decs[b].synthesize(feats[b, t]) for t in range(F, 2 * F)])
+        assert np.array_equal(second[b], want), ("unequal silence", b)
+    # trace build, free running
+    B, F = 3, 6
+    n = F * 160
+    feats = np.stack([synthetic_features(1700 + b, F) for b in range(B)])
+    gpu = LPCNetBatch(B, F)
+    gpu.set_multi(2)
+    gpu.enable_trace(True)
+    pcm = gpu.synthesize(feats)
+    for b in range(B):
+        dec = oracle.decoder(model, trace_cap=n)
+        want = np.concatenate([dec.synthesize(feats[b, t]) for t in range(F)])
+        assert np.array_equal(gpu.tap(b, 3, F).reshape(-1)[320:].astype(np.uint8), dec.trace_exc[:n - 320]), b
+        assert np.array_equal(gpu.tap(b, 4, F).reshape(-1)[320:], dec.trace_pcm[:n - 320]), b
+        assert np.array_equal(pcm[b], want), b
+    # teacher forced
+    rng = np.random.default_rng(23)
+    exc = np.clip(np.rint(128 + rng.normal(0, 30, (B, n))), 0, 255).astype(np.uint8)
+    gpu.reset()
+    gpu.force_excitation(exc, F)
+    gpu.synthesize(feats)
+    for b in range(B):
+        dec = oracle.decoder(model, trace_cap=n)
+        dec.force(exc[b, 320:])
+        for t in range(F):
+            dec.synthesize(feats[b, t])
+        logits = gpu.tap(b, 5, F).reshape(n, 256)[320:]
+        assert np.array_equal(logits, dec.forced_logits), (b, np.abs(logits - dec.forced_logits).max())
+
+
+def test_pair_kernel_other_models_and_selection(oracle):
+    """Recurrent-first association order and a model at the 12-slot z/r capacity through the pair kernel; a model that
+    needs the extended paths refuses the forced choice (it stays on the latency kernel)."""
+    from dss_amd import _lib, lpcnet
     from dss_amd.lpcnet import LPCNetBatch
     from dss_amd.lpcnet_weights import make_synthetic_weights, pack_blob
     feats = np.stack([synthetic_features(1500 + b, 5) for b in range(9)])
@@ -502,7 +549,33 @@ def test_multi_utterance_kernel_other_models(oracle):
         for blob in (synthetic_blob(0, gru_a_order=1), pack_blob(make_synthetic_weights(1))):
             lpcnet.load_model(blob)
             gpu = LPCNetBatch(9, 5)
-            gpu.set_multi(3)
+            gpu.set_multi(2)
             assert np.array_equal(gpu.synthesize(feats), _oracle_pcm(oracle, blob, feats))
+        lpcnet.load_model(synthetic_blob(0, skew=0.1))
+        gpu = LPCNetBatch(9, 5)
+        with pytest.raises(_lib.DssError, match="do not fit"):
+            gpu.set_multi(2)
     finally:
         lpcnet.load_model(synthetic_blob(0))
+
+
+def test_pair_kernel_is_chosen_beyond_one_utterance_per_cu(golden, model):
+    """600 utterances on 256 CUs: the automatic choice (pair kernel) and the forced latency kernel agree bit for bit with
+    each other and with the golden utterance; an odd count exercises the half-filled last workgroup at full scale."""
+    from dss_amd.lpcnet import LPCNetBatch
+    g = golden("lpcnet_self.npz")
+    B, F = 601, 30
+    feats = np.stack([synthetic_features(2, F)] * B)
+    feats[1::2] = synthetic_features(5, F)
+    gpu = LPCNetBatch(B, F)
+    gpu.enable_timing(True)
+    auto = gpu.synthesize(feats)
+    t_auto = gpu.kernel_ms(0)
+    gpu.reset()
+    gpu.set_multi(1)
+    gpu.enable_timing(True)
+    one = gpu.synthesize(feats)
+    t_one = gpu.kernel_ms(0)
+    assert np.array_equal(auto, one)
+    assert np.array_equal(auto[0], g["utt2_pcm"]) and np.array_equal(auto[600], g["utt2_pcm"])
+    print(f"601 x {F} frames: auto {t_auto:.1f} ms, one utterance per workgroup {t_one:.1f} ms")

@@ -8,14 +8,18 @@ from dss_amd.lpcnet import LPCNetBatch
 from dss_amd.lpcnet_weights import synthetic_features
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 F = 20
+MODE = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # utterances per workgroup: 1 (latency kernel), 2 (pair kernel)
 feats = np.stack([synthetic_features(b, F) for b in range(B)])
 gpu = LPCNetBatch(B, F)
+gpu.set_multi(MODE)
 gpu.enable_trace(2)
 gpu.synthesize(feats)
 n = (F - 2) * 160
 raw = np.empty((F * 160,), np.float32)
 names = ["P1 work", "wait A", "A->B (GRU A)", "B->C (GRU B)", "C->D (FC)", "P6 / idle"]
 _lib.check(gpu._L.dss_lpcnet_batch_tap(gpu._h, 0, 4, raw.ctypes.data, raw.size))   # trace_pcm holds the stamps
+if MODE == 2:
+    B = (B + 1) // 2                                       # one record per workgroup
 st = raw[: B * 6].reshape(B, 6) / n
 print("wave 7 (scalar role) view, cycles per sample, mean over utterances:")
 print("  " + "  ".join(f"{names[k]}={st[:, k].mean():8.1f}" for k in range(6)), " total", st.sum(axis=1).mean())
