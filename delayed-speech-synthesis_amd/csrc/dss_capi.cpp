@@ -198,7 +198,8 @@ static int check_header(const dss_blob_header &h)
     return DSS_OK;
 }
 
-extern "C" int dss_lpcnet_load_model(const void *blob, size_t len)
+// parse + validate a blob into a new HostModel (no lock, no device work)
+static int parse_blob(const void *blob, size_t len, HostModel **out)
 {
     if (!blob || len < sizeof(dss_blob_header)) { dss_set_error("blob too short"); return DSS_EINVAL; }
     HostModel *hm = new HostModel;
@@ -228,7 +229,16 @@ extern "C" int dss_lpcnet_load_model(const void *blob, size_t len)
     const int na = hm->h.gru_a, nb = hm->h.gru_b;
     const double floats = 3.0 * (3 * na) + (double)hm->h.sparse_nblocks * 32 + 3 * na + 3.0 * nb * (na + nb) + 2.0 * nb * 8 + 16;
     hm->bytes_per_sample = 4.0 * floats + 2.0 + 80.0 / 160.0;
-    std::lock_guard<std::mutex> lk(g_model_mu);
+    *out = hm;
+    return DSS_OK;
+}
+
+// caller holds g_model_mu
+static int load_blob_locked(const void *blob, size_t len)
+{
+    HostModel *hm = nullptr;
+    int rc = parse_blob(blob, len, &hm);
+    if (rc) return rc;
     // an earlier model stays alive exactly as long as decoder batches created from it exist (they hold its device
     // pointers); with none left it is freed here, otherwise when its last batch is destroyed
     if (g_model && g_model->refs == 0) free_model(g_model);
@@ -236,17 +246,36 @@ extern "C" int dss_lpcnet_load_model(const void *blob, size_t len)
     return DSS_OK;
 }
 
-extern "C" int dss_lpcnet_load_model_file(const char *path)
+extern "C" int dss_lpcnet_load_model(const void *blob, size_t len)
+{
+    HostModel *hm = nullptr;
+    int rc = parse_blob(blob, len, &hm);                    // the slow part outside the lock
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_model_mu);
+    if (g_model && g_model->refs == 0) free_model(g_model);
+    g_model = hm;
+    return DSS_OK;
+}
+
+static int read_file(const char *path, std::vector<char> &buf)
 {
     FILE *f = fopen(path, "rb");
     if (!f) { dss_set_error("cannot open %s", path); return DSS_EINVAL; }
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    std::vector<char> buf((size_t)n);
-    size_t got = fread(buf.data(), 1, (size_t)n, f);
+    buf.resize((size_t)(n > 0 ? n : 0));
+    size_t got = n > 0 ? fread(buf.data(), 1, (size_t)n, f) : 0;
     fclose(f);
-    if (got != (size_t)n) { dss_set_error("short read on %s", path); return DSS_EINVAL; }
+    if (n < 0 || got != (size_t)n) { dss_set_error("short read on %s", path); return DSS_EINVAL; }
+    return DSS_OK;
+}
+
+extern "C" int dss_lpcnet_load_model_file(const char *path)
+{
+    std::vector<char> buf;
+    int rc = read_file(path, buf);
+    if (rc) return rc;
     return dss_lpcnet_load_model(buf.data(), buf.size());
 }
 
@@ -581,17 +610,23 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
     return DSS_OK;
 }
 
-static int get_model(HostModel **out_hm, const DssModelDev **out)
+// Returns the current model and its copy on the calling thread's device.  With acquire set, the model's reference count
+// is taken while g_model_mu is still held, so a concurrent dss_lpcnet_load_model() cannot free it in between; the caller
+// then owns one reference (release_model()).
+static int load_blob_locked(const void *blob, size_t len);
+
+static int get_model(HostModel **out_hm, const DssModelDev **out, bool acquire)
 {
     int rc = ensure_device();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g_model_mu);
+    std::unique_lock<std::mutex> lk(g_model_mu);
     if (!g_model) {
         const char *path = getenv("DSS_LPCNET_WEIGHTS");
         if (!path) { dss_set_error("no LPCNet weights: call dss_lpcnet_load_model() or set DSS_LPCNET_WEIGHTS"); return DSS_ENOMODEL; }
-        g_model_mu.unlock();
-        rc = dss_lpcnet_load_model_file(path);
-        g_model_mu.lock();
+        std::vector<char> buf;
+        rc = read_file(path, buf);
+        if (rc) return rc;
+        rc = load_blob_locked(buf.data(), buf.size());
         if (rc) return rc;
     }
     HostModel *hm = g_model;
@@ -604,9 +639,16 @@ static int get_model(HostModel **out_hm, const DssModelDev **out)
         if (rc) return rc;
         hm->dev_ready[g_device] = 1;
     }
+    if (acquire) hm->refs++;
     *out_hm = hm;
     *out = &hm->dev[g_device];
     return DSS_OK;
+}
+
+static void release_model(HostModel *hm)
+{
+    std::lock_guard<std::mutex> lk(g_model_mu);
+    if (hm && --hm->refs == 0 && hm != g_model) free_model(hm);     // a superseded model dies with its last user
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -618,6 +660,7 @@ struct dss_lpcnet_batch {
     const DssModelDev *model;
     DssBatchDev d;
     int last_utts = 0, last_frames = 0;
+    int force_utts = 0, force_frames = 0;   // shape force_exc / trace_logits were sized for (dss_lpcnet_batch_force_excitation)
     int trace = 0, timing = 0;
     int pair = 0;                 // 0 auto, -1 never, 2 always: two utterances per workgroup (dss_lpcnet_batch_set_multi)
     float *d_feat = nullptr;      // staging for the host-buffer entry point
@@ -633,12 +676,11 @@ extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frame
 {
     if (max_utts <= 0 || max_frames <= 0) { dss_set_error("batch dims must be positive"); return nullptr; }
     HostModel *hm; const DssModelDev *m;
-    if (get_model(&hm, &m)) return nullptr;
+    if (get_model(&hm, &m, true)) return nullptr;            // holds one reference from here on (dropped by destroy)
     dss_lpcnet_batch *b = new dss_lpcnet_batch;
     memset(&b->d, 0, sizeof(b->d));
     b->device = g_device;
     b->host_model = hm;
-    { std::lock_guard<std::mutex> lk(g_model_mu); hm->refs++; }
     b->model = m;
     DssBatchDev &d = b->d;
     d.max_utts = max_utts; d.max_frames = max_frames;
@@ -686,11 +728,7 @@ extern "C" void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b)
                     d.fc0, d.trace_exc, d.trace_pcm, d.trace_logits, (void *)d.force_exc, b->d_feat, b->d_pcm, b->d_slots, b->d_counts};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 3; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
-    {
-        std::lock_guard<std::mutex> lk(g_model_mu);
-        HostModel *hm = b->host_model;
-        if (hm && --hm->refs == 0 && hm != g_model) free_model(hm);     // a superseded model dies with its last batch
-    }
+    release_model(b->host_model);
     delete b;
 }
 
@@ -733,6 +771,7 @@ extern "C" int dss_lpcnet_batch_force_excitation(dss_lpcnet_batch *b, const unsi
         if (b->d.force_exc) hipFree((void *)b->d.force_exc);
         if (b->d.trace_logits) hipFree(b->d.trace_logits);
         b->d.force_exc = nullptr; b->d.trace_logits = nullptr;
+        b->force_utts = b->force_frames = 0;
         return DSS_OK;
     }
     if (n_utts <= 0 || n_utts > b->d.max_utts || n_frames <= 0 || n_frames > b->d.max_frames) {
@@ -743,23 +782,25 @@ extern "C" int dss_lpcnet_batch_force_excitation(dss_lpcnet_batch *b, const unsi
     if (b->d.force_exc) hipFree((void *)b->d.force_exc);
     if (b->d.trace_logits) hipFree(b->d.trace_logits);
     b->d.force_exc = nullptr; b->d.trace_logits = nullptr;
+    b->force_utts = b->force_frames = 0;
     unsigned char *de = nullptr;
     if (dev_upload<unsigned char>(exc, n, &de)) return DSS_ENOMEM;
     b->d.force_exc = de;
     if (dev_alloc<float>(n * 256, &b->d.trace_logits)) return DSS_ENOMEM;
+    b->force_utts = n_utts; b->force_frames = n_frames;
     return DSS_OK;
 }
 
 extern "C" int dss_lpcnet_model_info(int *fast_path, int *zr_slots_max, int *h_slots_max, int *h_lds_bytes, int *gru_a_order)
 {
     HostModel *hm; const DssModelDev *m;
-    int rc = get_model(&hm, &m);
+    int rc = get_model(&hm, &m, true);
     if (rc) return rc;
     int hmax = 0;
     // recomputed from the blob (the device struct keeps only what the kernels need)
     {
         BlobView v;
-        if (view_blob(hm->blob, hm->h, v)) return DSS_EINVAL;
+        if (view_blob(hm->blob, hm->h, v)) { release_model(hm); return DSS_EINVAL; }
         const int G = hm->h.gru_a / 8;
         long pos = 0;
         for (int g = 0; g < 3 * G; ++g) { const int c = v.gru_a_idx[pos]; if (g >= 2 * G) hmax = std::max(hmax, c); pos += 1 + c; }
@@ -769,6 +810,7 @@ extern "C" int dss_lpcnet_model_info(int *fast_path, int *zr_slots_max, int *h_s
     if (h_slots_max) *h_slots_max = hmax;
     if (h_lds_bytes) *h_lds_bytes = m->hblk_floats * 4;
     if (gru_a_order) *gru_a_order = hm->h.gru_a_order;
+    release_model(hm);
     return DSS_OK;
 }
 
@@ -813,6 +855,15 @@ static int check_batch_shape(dss_lpcnet_batch *b, int n_utts, int n_frames, int 
 static int run_batch(dss_lpcnet_batch *b, const float *d_features, int n_utts, int n_frames, int feat_stride, short *d_pcm,
                      hipStream_t s)
 {
+    // the kernels index the forced excitation and the logit trace with the CALL's shape: it must be the shape they were
+    // sized for, and a uniform call (the trace build would launch a ragged one as if every row were full)
+    if (b->d.force_exc || b->d.trace_logits) {
+        if (n_utts != b->force_utts || n_frames != b->force_frames || b->d.slot_of || b->d.count_of) {
+            dss_set_error("teacher forcing was set up for %d x %d frames, uniform calls only; this call is %d x %d%s",
+                          b->force_utts, b->force_frames, n_utts, n_frames, (b->d.slot_of || b->d.count_of) ? " (ragged)" : "");
+            return DSS_EINVAL;
+        }
+    }
     if (b->timing) DSS_HIP_CHECK(hipEventRecord(b->ev[0], s));
     int rc = dss_launch_frame_network(*b->model, b->d, d_features, n_utts, n_frames, feat_stride, s);
     if (rc) return rc;

@@ -72,78 +72,111 @@ __device__ __forceinline__ f32x2 dss_pk_mul_hi(f32x2 w, f32x2 x)
     return r;
 }
 // One 8x4 block (or four consecutive dense inputs) of ONE dependent chain, software-pipelined: the four sums of this
-// block's products P (formed one step earlier, in place, where the inputs were) alternate with the four products of
-// the NEXT block, X <- W * X, so that every dependent v_pk_add_f32 (8.9 cycles of latency) has an independent
-// multiplication behind it.  W = (w0, w1) (w2, w3); X0..X3 = the (A, B) pairs of inputs 0..3.
-#define DSS_PK_STEP4(ACC, P0, P1, P2, P3, X0, X1, X2, X3, WLO, WHI)                              \
+// block's products P (formed one step earlier) alternate with the four products Q of the NEXT block, so that every
+// dependent v_pk_add_f32 (8.9 cycles of latency) has an independent multiplication behind it.  W = (w0, w1) (w2, w3);
+// X0..X3 = the (A, B) pairs of the next block's inputs 0..3.  Products go to registers of their own (the inputs are
+// halves of 128-bit LDS reads: modified in place, half of them were copied first).
+#define DSS_PK_STEP4(ACC, P, Q, X, WLO, WHI)                                                     \
     asm("v_pk_add_f32 %[a], %[a], %[p0]\n\t"                                                     \
-        "v_pk_mul_f32 %[x0], %[wl], %[x0] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[q0], %[wl], %[x0] op_sel_hi:[0,1]\n\t"                                   \
         "v_pk_add_f32 %[a], %[a], %[p1]\n\t"                                                     \
-        "v_pk_mul_f32 %[x1], %[wl], %[x1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_mul_f32 %[q1], %[wl], %[x1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
         "v_pk_add_f32 %[a], %[a], %[p2]\n\t"                                                     \
-        "v_pk_mul_f32 %[x2], %[wh], %[x2] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[q2], %[wh], %[x2] op_sel_hi:[0,1]\n\t"                                   \
         "v_pk_add_f32 %[a], %[a], %[p3]\n\t"                                                     \
-        "v_pk_mul_f32 %[x3], %[wh], %[x3] op_sel:[1,0] op_sel_hi:[1,1]"                          \
-        : [a] "+v"(ACC), [x0] "+v"(X0), [x1] "+v"(X1), [x2] "+v"(X2), [x3] "+v"(X3)              \
-        : [p0] "v"(P0), [p1] "v"(P1), [p2] "v"(P2), [p3] "v"(P3), [wl] "v"(WLO), [wh] "v"(WHI))
+        "v_pk_mul_f32 %[q3], %[wh], %[x3] op_sel:[1,0] op_sel_hi:[1,1]"                          \
+        : [a] "+v"(ACC), [q0] "=&v"((Q)[0]), [q1] "=&v"((Q)[1]), [q2] "=&v"((Q)[2]), [q3] "=&v"((Q)[3]) \
+        : [p0] "v"((P)[0]), [p1] "v"((P)[1]), [p2] "v"((P)[2]), [p3] "v"((P)[3]),                \
+          [x0] "v"((X).a.lo), [x1] "v"((X).a.hi), [x2] "v"((X).c.lo), [x3] "v"((X).c.hi), [wl] "v"(WLO), [wh] "v"(WHI))
 // the first block's products (nothing to add yet) and the last block's sums (nothing left to multiply)
-#define DSS_PK_MUL4(X0, X1, X2, X3, WLO, WHI)                                                    \
-    asm("v_pk_mul_f32 %[x0], %[wl], %[x0] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_mul_f32 %[x1], %[wl], %[x1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
-        "v_pk_mul_f32 %[x2], %[wh], %[x2] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_mul_f32 %[x3], %[wh], %[x3] op_sel:[1,0] op_sel_hi:[1,1]"                          \
-        : [x0] "+v"(X0), [x1] "+v"(X1), [x2] "+v"(X2), [x3] "+v"(X3)                             \
-        : [wl] "v"(WLO), [wh] "v"(WHI))
-#define DSS_PK_ADD4(ACC, P0, P1, P2, P3)                                                         \
+#define DSS_PK_MUL4(Q, X, WLO, WHI)                                                              \
+    asm("v_pk_mul_f32 %[q0], %[wl], %[x0] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[q1], %[wl], %[x1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_mul_f32 %[q2], %[wh], %[x2] op_sel_hi:[0,1]\n\t"                                   \
+        "v_pk_mul_f32 %[q3], %[wh], %[x3] op_sel:[1,0] op_sel_hi:[1,1]"                          \
+        : [q0] "=&v"((Q)[0]), [q1] "=&v"((Q)[1]), [q2] "=&v"((Q)[2]), [q3] "=&v"((Q)[3])         \
+        : [x0] "v"((X).a.lo), [x1] "v"((X).a.hi), [x2] "v"((X).c.lo), [x3] "v"((X).c.hi), [wl] "v"(WLO), [wh] "v"(WHI))
+#define DSS_PK_ADD4(ACC, P)                                                                      \
     asm("v_pk_add_f32 %[a], %[a], %[p0]\n\t"                                                     \
         "v_pk_add_f32 %[a], %[a], %[p1]\n\t"                                                     \
         "v_pk_add_f32 %[a], %[a], %[p2]\n\t"                                                     \
         "v_pk_add_f32 %[a], %[a], %[p3]"                                                         \
         : [a] "+v"(ACC)                                                                          \
-        : [p0] "v"(P0), [p1] "v"(P1), [p2] "v"(P2), [p3] "v"(P3))
+        : [p0] "v"((P)[0]), [p1] "v"((P)[1]), [p2] "v"((P)[2]), [p3] "v"((P)[3]))
 // One 8x4 block of the z gate and one of the r gate: two independent chains, so the sums of one hide the latency of the
-// other and the products need no pipelining across blocks (they are formed in place, where the inputs were).
-#define DSS_PK_ZR4(AZ, AR, XZ0, XZ1, XZ2, XZ3, XR0, XR1, XR2, XR3, WZLO, WZHI, WRLO, WRHI)       \
-    asm("v_pk_mul_f32 %[z0], %[wzl], %[z0] op_sel_hi:[0,1]\n\t"                                  \
-        "v_pk_mul_f32 %[r0], %[wrl], %[r0] op_sel_hi:[0,1]\n\t"                                  \
-        "v_pk_mul_f32 %[z1], %[wzl], %[z1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                     \
-        "v_pk_mul_f32 %[r1], %[wrl], %[r1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                     \
-        "v_pk_add_f32 %[az], %[az], %[z0]\n\t"                                                   \
+// other and the products need no pipelining across blocks.  T[0..3] z products, T[4..7] r products (temporaries).
+#define DSS_PK_ZR_MUL(T, XZ, XR, WZLO, WZHI, WRLO, WRHI)                                         \
+    asm("v_pk_mul_f32 %[z0], %[wzl], %[xz0] op_sel_hi:[0,1]\n\t"                                 \
+        "v_pk_mul_f32 %[r0], %[wrl], %[xr0] op_sel_hi:[0,1]\n\t"                                 \
+        "v_pk_mul_f32 %[z1], %[wzl], %[xz1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                    \
+        "v_pk_mul_f32 %[r1], %[wrl], %[xr1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                    \
+        "v_pk_mul_f32 %[z2], %[wzh], %[xz2] op_sel_hi:[0,1]\n\t"                                 \
+        "v_pk_mul_f32 %[r2], %[wrh], %[xr2] op_sel_hi:[0,1]\n\t"                                 \
+        "v_pk_mul_f32 %[z3], %[wzh], %[xz3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                    \
+        "v_pk_mul_f32 %[r3], %[wrh], %[xr3] op_sel:[1,0] op_sel_hi:[1,1]"                        \
+        : [z0] "=&v"((T)[0]), [z1] "=&v"((T)[1]), [z2] "=&v"((T)[2]), [z3] "=&v"((T)[3]),        \
+          [r0] "=&v"((T)[4]), [r1] "=&v"((T)[5]), [r2] "=&v"((T)[6]), [r3] "=&v"((T)[7])         \
+        : [xz0] "v"((XZ).a.lo), [xz1] "v"((XZ).a.hi), [xz2] "v"((XZ).c.lo), [xz3] "v"((XZ).c.hi), \
+          [xr0] "v"((XR).a.lo), [xr1] "v"((XR).a.hi), [xr2] "v"((XR).c.lo), [xr3] "v"((XR).c.hi), \
+          [wzl] "v"(WZLO), [wzh] "v"(WZHI), [wrl] "v"(WRLO), [wrh] "v"(WRHI))
+#define DSS_PK_ZR_ADD(AZ, AR, T)                                                                 \
+    asm("v_pk_add_f32 %[az], %[az], %[z0]\n\t"                                                   \
         "v_pk_add_f32 %[ar], %[ar], %[r0]\n\t"                                                   \
-        "v_pk_mul_f32 %[z2], %[wzh], %[z2] op_sel_hi:[0,1]\n\t"                                  \
-        "v_pk_mul_f32 %[r2], %[wrh], %[r2] op_sel_hi:[0,1]\n\t"                                  \
         "v_pk_add_f32 %[az], %[az], %[z1]\n\t"                                                   \
         "v_pk_add_f32 %[ar], %[ar], %[r1]\n\t"                                                   \
-        "v_pk_mul_f32 %[z3], %[wzh], %[z3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                     \
-        "v_pk_mul_f32 %[r3], %[wrh], %[r3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                     \
         "v_pk_add_f32 %[az], %[az], %[z2]\n\t"                                                   \
         "v_pk_add_f32 %[ar], %[ar], %[r2]\n\t"                                                   \
         "v_pk_add_f32 %[az], %[az], %[z3]\n\t"                                                   \
         "v_pk_add_f32 %[ar], %[ar], %[r3]"                                                       \
-        : [az] "+v"(AZ), [ar] "+v"(AR), [z0] "+v"(XZ0), [z1] "+v"(XZ1), [z2] "+v"(XZ2), [z3] "+v"(XZ3),  \
-          [r0] "+v"(XR0), [r1] "+v"(XR1), [r2] "+v"(XR2), [r3] "+v"(XR3)                         \
-        : [wzl] "v"(WZLO), [wzh] "v"(WZHI), [wrl] "v"(WRLO), [wrh] "v"(WRHI))
-// One input of the two dual-FC layers for both utterances: S0 += w0 * (bA, bB), S1 += w1 * (bA, bB); four inputs per block
-#define DSS_PK_FC4(S0, S1, T0, T1, T2, T3, U0, U1, U2, U3, W0, W1, W2, W3)                       \
+        : [az] "+v"(AZ), [ar] "+v"(AR)                                                           \
+        : [z0] "v"((T)[0]), [z1] "v"((T)[1]), [z2] "v"((T)[2]), [z3] "v"((T)[3]),                \
+          [r0] "v"((T)[4]), [r1] "v"((T)[5]), [r2] "v"((T)[6]), [r3] "v"((T)[7]))
+#define DSS_PK_ZR4(AZ, AR, T, XZ, XR, WZLO, WZHI, WRLO, WRHI)                                    \
+    asm("v_pk_mul_f32 %[z0], %[wzl], %[xz0] op_sel_hi:[0,1]\n\t"                                 \
+        "v_pk_mul_f32 %[r0], %[wrl], %[xr0] op_sel_hi:[0,1]\n\t"                                 \
+        "v_pk_mul_f32 %[z1], %[wzl], %[xz1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                    \
+        "v_pk_mul_f32 %[r1], %[wrl], %[xr1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                    \
+        "v_pk_add_f32 %[az], %[az], %[z0]\n\t"                                                   \
+        "v_pk_add_f32 %[ar], %[ar], %[r0]\n\t"                                                   \
+        "v_pk_mul_f32 %[z2], %[wzh], %[xz2] op_sel_hi:[0,1]\n\t"                                 \
+        "v_pk_mul_f32 %[r2], %[wrh], %[xr2] op_sel_hi:[0,1]\n\t"                                 \
+        "v_pk_add_f32 %[az], %[az], %[z1]\n\t"                                                   \
+        "v_pk_add_f32 %[ar], %[ar], %[r1]\n\t"                                                   \
+        "v_pk_mul_f32 %[z3], %[wzh], %[xz3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                    \
+        "v_pk_mul_f32 %[r3], %[wrh], %[xr3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                    \
+        "v_pk_add_f32 %[az], %[az], %[z2]\n\t"                                                   \
+        "v_pk_add_f32 %[ar], %[ar], %[r2]\n\t"                                                   \
+        "v_pk_add_f32 %[az], %[az], %[z3]\n\t"                                                   \
+        "v_pk_add_f32 %[ar], %[ar], %[r3]"                                                       \
+        : [az] "+v"(AZ), [ar] "+v"(AR),                                                          \
+          [z0] "=&v"((T)[0]), [z1] "=&v"((T)[1]), [z2] "=&v"((T)[2]), [z3] "=&v"((T)[3]),        \
+          [r0] "=&v"((T)[4]), [r1] "=&v"((T)[5]), [r2] "=&v"((T)[6]), [r3] "=&v"((T)[7])         \
+        : [xz0] "v"((XZ).a.lo), [xz1] "v"((XZ).a.hi), [xz2] "v"((XZ).c.lo), [xz3] "v"((XZ).c.hi), \
+          [xr0] "v"((XR).a.lo), [xr1] "v"((XR).a.hi), [xr2] "v"((XR).c.lo), [xr3] "v"((XR).c.hi), \
+          [wzl] "v"(WZLO), [wzh] "v"(WZHI), [wrl] "v"(WRLO), [wrh] "v"(WRHI))
+// One block of four inputs of the two dual-FC layers for both utterances: S0 += w0 * (bA, bB), S1 += w1 * (bA, bB)
+#define DSS_PK_FC4(S0, S1, T, U, W0, W1, W2, W3)                                                 \
     asm("v_pk_mul_f32 %[t0], %[w0], %[u0] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_mul_f32 %[u0], %[w0], %[u0] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_mul_f32 %[v0], %[w0], %[u0] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
         "v_pk_mul_f32 %[t1], %[w1], %[u1] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_mul_f32 %[u1], %[w1], %[u1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_mul_f32 %[v1], %[w1], %[u1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
         "v_pk_add_f32 %[s0], %[s0], %[t0]\n\t"                                                   \
-        "v_pk_add_f32 %[s1], %[s1], %[u0]\n\t"                                                   \
+        "v_pk_add_f32 %[s1], %[s1], %[v0]\n\t"                                                   \
         "v_pk_mul_f32 %[t2], %[w2], %[u2] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_mul_f32 %[u2], %[w2], %[u2] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_mul_f32 %[v2], %[w2], %[u2] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
         "v_pk_add_f32 %[s0], %[s0], %[t1]\n\t"                                                   \
-        "v_pk_add_f32 %[s1], %[s1], %[u1]\n\t"                                                   \
+        "v_pk_add_f32 %[s1], %[s1], %[v1]\n\t"                                                   \
         "v_pk_mul_f32 %[t3], %[w3], %[u3] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_mul_f32 %[u3], %[w3], %[u3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
+        "v_pk_mul_f32 %[v3], %[w3], %[u3] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
         "v_pk_add_f32 %[s0], %[s0], %[t2]\n\t"                                                   \
-        "v_pk_add_f32 %[s1], %[s1], %[u2]\n\t"                                                   \
+        "v_pk_add_f32 %[s1], %[s1], %[v2]\n\t"                                                   \
         "v_pk_add_f32 %[s0], %[s0], %[t3]\n\t"                                                   \
-        "v_pk_add_f32 %[s1], %[s1], %[u3]"                                                       \
-        : [s0] "+v"(S0), [s1] "+v"(S1), [t0] "=&v"(T0), [t1] "=&v"(T1), [t2] "=&v"(T2), [t3] "=&v"(T3),  \
-          [u0] "+v"(U0), [u1] "+v"(U1), [u2] "+v"(U2), [u3] "+v"(U3)                             \
-        : [w0] "v"(W0), [w1] "v"(W1), [w2] "v"(W2), [w3] "v"(W3))
+        "v_pk_add_f32 %[s1], %[s1], %[v3]"                                                       \
+        : [s0] "+v"(S0), [s1] "+v"(S1),                                                          \
+          [t0] "=&v"((T)[0]), [t1] "=&v"((T)[1]), [t2] "=&v"((T)[2]), [t3] "=&v"((T)[3]),        \
+          [v0] "=&v"((T)[4]), [v1] "=&v"((T)[5]), [v2] "=&v"((T)[6]), [v3] "=&v"((T)[7])         \
+        : [u0] "v"((U).a.lo), [u1] "v"((U).a.hi), [u2] "v"((U).c.lo), [u3] "v"((U).c.hi),        \
+          [w0] "v"(W0), [w1] "v"(W1), [w2] "v"(W2), [w3] "v"(W3))
 
 // vec.h tanh_approx on an (A, B) pair: per half exactly the operations of dss_tanh_approx, in its order
 __device__ __forceinline__ f32x2 dss_tanh_pk(const float *tab, f32x2 x)
@@ -162,13 +195,40 @@ __device__ __forceinline__ f32x2 dss_tanh_pk(const float *tab, f32x2 x)
     return sg * r;
 }
 __device__ __forceinline__ f32x2 dss_sigmoid_pk(const float *tab, f32x2 x) { return .5f + .5f * dss_tanh_pk(tab, .5f * x); }
+// two independent pairs, all four table reads issued before any is consumed (same arithmetic per element)
+__device__ __forceinline__ void dss_tanh_pk2(const float *tab, f32x2 x, f32x2 w, f32x2 &ox, f32x2 &ow)
+{
+    const bool n0 = x.x < 0, n1 = x.y < 0, n2 = w.x < 0, n3 = w.y < 0;
+    f32x2 a = {n0 ? -x.x : x.x, n1 ? -x.y : x.y}, c = {n2 ? -w.x : w.x, n3 ? -w.y : w.y};
+    const f32x2 sa = {n0 ? -1.f : 1.f, n1 ? -1.f : 1.f}, sc = {n2 ? -1.f : 1.f, n3 ? -1.f : 1.f};
+    const f32x2 ta = .5f + 25 * a, tc = .5f + 25 * c;
+    int i0 = (int)floorf(ta.x), i1 = (int)floorf(ta.y), i2 = (int)floorf(tc.x), i3 = (int)floorf(tc.y);
+    i0 = i0 < 0 ? 0 : i0; i0 = i0 > 200 ? 200 : i0;
+    i1 = i1 < 0 ? 0 : i1; i1 = i1 > 200 ? 200 : i1;
+    i2 = i2 < 0 ? 0 : i2; i2 = i2 > 200 ? 200 : i2;
+    i3 = i3 < 0 ? 0 : i3; i3 = i3 > 200 ? 200 : i3;
+    const f32x2 ya = {tab[i0], tab[i1]}, yc = {tab[i2], tab[i3]};
+    a -= .04f * (f32x2){(float)i0, (float)i1};
+    c -= .04f * (f32x2){(float)i2, (float)i3};
+    const f32x2 da = 1 - ya * ya, dc = 1 - yc * yc;
+    const f32x2 ra = ya + a * da * (1 - ya * a), rc = yc + c * dc * (1 - yc * c);
+    ox = sa * ra;
+    ow = sc * rc;
+}
+__device__ __forceinline__ void dss_sigmoid_pk2(const float *tab, f32x2 x, f32x2 w, f32x2 &ox, f32x2 &ow)
+{
+    f32x2 tx, tw;
+    dss_tanh_pk2(tab, .5f * x, .5f * w, tx, tw);
+    ox = .5f + .5f * tx;
+    ow = .5f + .5f * tw;
+}
 
 // a pair buffer of one 8x4 block: the block's four inputs for both utterances (two ds_read_b128)
-struct PairX { f32x2 v[4]; };
+struct PairX { f32x4 a, c; };          // a = inputs 0, 1; c = inputs 2, 3; each as (A, B)
 __device__ __forceinline__ void dss_pair_loadx(PairX &q, const char *p)
 {
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), c = *reinterpret_cast<const f32x4 *>(p + 16);
-    q.v[0] = a.lo; q.v[1] = a.hi; q.v[2] = c.lo; q.v[3] = c.hi;
+    q.a = *reinterpret_cast<const f32x4 *>(p);
+    q.c = *reinterpret_cast<const f32x4 *>(p + 16);
 }
 
 // Speculation for one candidate excitation value and both utterances: the output sample, the next LPC prediction (the
@@ -230,19 +290,18 @@ __device__ __forceinline__ void dss_pair_job_init(PairLds &L, const DssBatchDev 
         HW[BUF] = *reinterpret_cast<const f32x4 *>(hw + (S) * 128);                              \
         dss_pair_loadx(HX[BUF], xbase + DSS_H_COL(S) * 32);                                      \
     }
-#define DSS_PH_STEP(S)                                                                           \
-    DSS_PK_STEP4(ah, HX[(S) % 3].v[0], HX[(S) % 3].v[1], HX[(S) % 3].v[2], HX[(S) % 3].v[3],     \
-                 HX[((S) + 1) % 3].v[0], HX[((S) + 1) % 3].v[1], HX[((S) + 1) % 3].v[2], HX[((S) + 1) % 3].v[3], \
-                 HW[((S) + 1) % 3].lo, HW[((S) + 1) % 3].hi)
+// block S: sums of its products (in HP[S & 1]), products of block S+1 (into HP[(S + 1) & 1])
+#define DSS_PH_STEP(S) DSS_PK_STEP4(ah, HP[(S) & 1], HP[((S) + 1) & 1], HX[((S) + 1) % 3], HW[((S) + 1) % 3].lo, HW[((S) + 1) % 3].hi)
 #define DSS_PH_CHAIN(XBUF)                                                                       \
     {                                                                                            \
         const char *xbase = reinterpret_cast<const char *>(XBUF);                                \
         f32x4 HW[3];                                                                             \
         PairX HX[3];                                                                             \
+        f32x2 HP[2][4];                                                                          \
         f32x2 ah = rbh2 + dgh2 * *reinterpret_cast<const f32x2 *>(xbase + uh * 8);               \
         DSS_PH_LOAD(0, 0)                                                                        \
         DSS_PH_LOAD(1, 1)                                                                        \
-        DSS_PK_MUL4(HX[0].v[0], HX[0].v[1], HX[0].v[2], HX[0].v[3], HW[0].lo, HW[0].hi);         \
+        DSS_PK_MUL4(HP[0], HX[0], HW[0].lo, HW[0].hi);                                           \
         /* nh is even: blocks s and s+1 exist whenever s < nh, one test per pair.  (No break: the asm blocks are      \
            convergent calls, and a loop with a data-dependent exit around them is not unrolled.) */                 \
         _Pragma("unroll") for (int s = 0; s < HC; s += 2) {                                      \
@@ -257,7 +316,7 @@ __device__ __forceinline__ void dss_pair_job_init(PairLds &L, const DssBatchDev 
                     __builtin_amdgcn_sched_barrier(0);                                           \
                     DSS_PH_STEP(s + 1);                                                          \
                 } else {                                                                         \
-                    DSS_PK_ADD4(ah, HX[(s + 1) % 3].v[0], HX[(s + 1) % 3].v[1], HX[(s + 1) % 3].v[2], HX[(s + 1) % 3].v[3]); \
+                    DSS_PK_ADD4(ah, HP[(s + 1) & 1]);                                            \
                 }                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                               \
             }                                                                                    \
@@ -268,32 +327,30 @@ __device__ __forceinline__ void dss_pair_job_init(PairLds &L, const DssBatchDev 
 // GRU B: the chain of one row for both utterances over NBLK blocks of four inputs.  Blocks below G0 take their weights
 // from this lane's registers (WB[k] = inputs 2k, 2k+1), blocks from G0 on from LDS (row-major records, fetched with the
 // state pairs); the new GRU A state pairs come from LDS (same address in every lane: broadcast).  Everything is fetched
-// three blocks ahead of the block being summed; DSS_PGB_HEAD issues the first three fetches (wave 7: under its wait).
+// two blocks ahead of the block being summed; DSS_PGB_HEAD issues the first two fetches (wave 7: under its wait).
 #define DSS_PGB_LOAD(G, G0)                                                                      \
     {                                                                                            \
-        dss_pair_loadx(GX[(G) & 3], an + 32 * (G));                                              \
-        if ((G) >= (G0)) TW[(G) & 3] = *reinterpret_cast<const f32x4 *>(wl + 16 * ((G) - (G0))); \
+        dss_pair_loadx(GX[(G) % 3], an + 32 * (G));                                              \
+        if ((G) >= (G0)) TW[(G) % 3] = *reinterpret_cast<const f32x4 *>(wl + 16 * ((G) - (G0))); \
     }
-#define DSS_PGB_WLO(G, G0) ((G) < (G0) ? WB[(G) < (G0) ? 2 * (G) : 0] : TW[(G) & 3].lo)
-#define DSS_PGB_WHI(G, G0) ((G) < (G0) ? WB[(G) < (G0) ? 2 * (G) + 1 : 0] : TW[(G) & 3].hi)
+#define DSS_PGB_WLO(G, G0) ((G) < (G0) ? WB[(G) < (G0) ? 2 * (G) : 0] : TW[(G) % 3].lo)
+#define DSS_PGB_WHI(G, G0) ((G) < (G0) ? WB[(G) < (G0) ? 2 * (G) + 1 : 0] : TW[(G) % 3].hi)
 #define DSS_PGB_HEAD(G0)                                                                         \
-    PairX GX[4];                                                                                 \
-    f32x4 TW[4];                                                                                 \
+    PairX GX[3];                                                                                 \
+    f32x4 TW[3];                                                                                 \
+    f32x2 GP[2][4];                                                                              \
     DSS_PGB_LOAD(0, G0)                                                                          \
-    DSS_PGB_LOAD(1, G0)                                                                          \
-    DSS_PGB_LOAD(2, G0)
+    DSS_PGB_LOAD(1, G0)
 #define DSS_PGB_RUN(NBLK, G0)                                                                    \
     {                                                                                            \
-        DSS_PK_MUL4(GX[0].v[0], GX[0].v[1], GX[0].v[2], GX[0].v[3], DSS_PGB_WLO(0, G0), DSS_PGB_WHI(0, G0)); \
+        DSS_PK_MUL4(GP[0], GX[0], DSS_PGB_WLO(0, G0), DSS_PGB_WHI(0, G0));                       \
         _Pragma("unroll") for (int g = 0; g < (NBLK); ++g) {                                     \
-            if (g + 3 < (NBLK)) DSS_PGB_LOAD(g + 3, G0)                                          \
+            if (g + 2 < (NBLK)) DSS_PGB_LOAD(g + 2, G0)                                          \
             __builtin_amdgcn_sched_barrier(0);                                                   \
             if (g + 1 < (NBLK))                                                                  \
-                DSS_PK_STEP4(acc, GX[g & 3].v[0], GX[g & 3].v[1], GX[g & 3].v[2], GX[g & 3].v[3], \
-                             GX[(g + 1) & 3].v[0], GX[(g + 1) & 3].v[1], GX[(g + 1) & 3].v[2], GX[(g + 1) & 3].v[3], \
-                             DSS_PGB_WLO(g + 1, G0), DSS_PGB_WHI(g + 1, G0));                    \
+                DSS_PK_STEP4(acc, GP[g & 1], GP[(g + 1) & 1], GX[(g + 1) % 3], DSS_PGB_WLO(g + 1, G0), DSS_PGB_WHI(g + 1, G0)); \
             else                                                                                 \
-                DSS_PK_ADD4(acc, GX[g & 3].v[0], GX[g & 3].v[1], GX[g & 3].v[2], GX[g & 3].v[3]); \
+                DSS_PK_ADD4(acc, GP[g & 1]);                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
     }
@@ -386,6 +443,8 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
             const f32x2 cr = {foa[(unsigned)(NA + unit)], fob[(unsigned)(NA + unit)]};
             const f32x2 ch = {foa[(unsigned)(2 * NA + unit)], fob[(unsigned)(2 * NA + unit)]};
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
+                // waves 4, 5 carry the longest z/r lists and share their SIMDs with waves 0, 1: they go first between D and B
+                if (!HAS_FC) __builtin_amdgcn_s_setprio(1);
                 // keep the packed column ids opaque so the per-slot unpacking is not hoisted out of the sample loop
 #pragma unroll
                 for (int k = 0; k < (2 * ZRL + 3) / 4; ++k) asm volatile("" : "+v"(PZ[k]));
@@ -422,11 +481,25 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
                 const f32x3 esb = *reinterpret_cast<const f32x3 *>(m.embed_lane[0] + ((unsigned)sib * NA + (unsigned)tid) * 3);
                 const f32x3 epb = *reinterpret_cast<const f32x3 *>(m.embed_lane[1] + ((unsigned)pib * NA + (unsigned)tid) * 3);
                 const f32x3 eeb = *reinterpret_cast<const f32x3 *>(m.embed_lane[2] + ((unsigned)eib * NA + (unsigned)tid) * 3);
-                // first z/r block's state pairs: independent of the embedding rows, fetched under their latency
+                // The first two z/r blocks' products do not depend on the embedding rows: formed under their latency.
                 const char *xb = reinterpret_cast<const char *>(L.state_a[cur]);
                 PairX XZ[2], XR[2];
+                f32x2 T0[8], T1[8], TT[8];
                 dss_pair_loadx(XZ[0], xb + DSS_ZR_COL(0) * 32);
                 dss_pair_loadx(XR[0], xb + DSS_ZR_COL(ZRL) * 32);
+                dss_pair_loadx(XZ[1], xb + DSS_ZR_COL(1) * 32);
+                dss_pair_loadx(XR[1], xb + DSS_ZR_COL(ZRL + 1) * 32);
+                DSS_PK_ZR_MUL(T0, XZ[0], XR[0], WZ[0].lo, WZ[0].hi, WZ[ZRC].lo, WZ[ZRC].hi);
+                if (2 < nzr) {
+                    dss_pair_loadx(XZ[0], xb + DSS_ZR_COL(2) * 32);
+                    dss_pair_loadx(XR[0], xb + DSS_ZR_COL(ZRL + 2) * 32);
+                }
+                DSS_PK_ZR_MUL(T1, XZ[1], XR[1], WZ[1].lo, WZ[1].hi, WZ[ZRC + 1].lo, WZ[ZRC + 1].hi);
+                if (2 < nzr) {
+                    dss_pair_loadx(XZ[1], xb + DSS_ZR_COL(3) * 32);
+                    dss_pair_loadx(XR[1], xb + DSS_ZR_COL(ZRL + 3) * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[0] += t - ta; ta = t; }
                 f32x2 gz, gr, gh;                                                     // compute_gru_a_input
                 gz.x = ((cz.x + esa.x) + epa.x) + eea.x;  gz.y = ((cz.y + esb.x) + epb.x) + eeb.x;
@@ -436,33 +509,39 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
                 // nnet.c 2019-20 (blob flag): the blocks first, the input last
                 if (!recur_first) { az = az + gz; ar = ar + gr; }
                 if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[1] += t - ta; ta = t; }
+                if (0 < nzr) {                                       // (a wave whose row groups have no z/r blocks at all)
+                    DSS_PK_ZR_ADD(az, ar, T0);
+                    DSS_PK_ZR_ADD(az, ar, T1);
+                }
 #pragma unroll
-                for (int s = 0; s < ZRC; s += 2) {
-                    if (s < nzr) {                                   // nzr is even: slots s and s+1 exist
-                        dss_pair_loadx(XZ[1], xb + DSS_ZR_COL(s + 1) * 32);
-                        dss_pair_loadx(XR[1], xb + DSS_ZR_COL(ZRL + s + 1) * 32);
+                for (int s = 2; s < ZRC; s += 2) {
+                    if (s < nzr) {                                   // nzr is even: slots s and s+1 exist; their inputs are in flight
                         __builtin_amdgcn_sched_barrier(0);
-                        DSS_PK_ZR4(az, ar, XZ[0].v[0], XZ[0].v[1], XZ[0].v[2], XZ[0].v[3], XR[0].v[0], XR[0].v[1], XR[0].v[2], XR[0].v[3],
-                                   WZ[s].lo, WZ[s].hi, WZ[ZRC + s].lo, WZ[ZRC + s].hi);
+                        DSS_PK_ZR4(az, ar, TT, XZ[0], XR[0], WZ[s].lo, WZ[s].hi, WZ[ZRC + s].lo, WZ[ZRC + s].hi);
                         __builtin_amdgcn_sched_barrier(0);
                         if (s + 2 < ZRC && s + 2 < nzr) {
                             dss_pair_loadx(XZ[0], xb + DSS_ZR_COL(s + 2 < ZRC ? s + 2 : 0) * 32);
                             dss_pair_loadx(XR[0], xb + DSS_ZR_COL(ZRL + (s + 2 < ZRC ? s + 2 : 0)) * 32);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        DSS_PK_ZR4(az, ar, XZ[1].v[0], XZ[1].v[1], XZ[1].v[2], XZ[1].v[3], XR[1].v[0], XR[1].v[1], XR[1].v[2], XR[1].v[3],
-                                   WZ[s + 1].lo, WZ[s + 1].hi, WZ[ZRC + s + 1].lo, WZ[ZRC + s + 1].hi);
+                        DSS_PK_ZR4(az, ar, TT, XZ[1], XR[1], WZ[s + 1].lo, WZ[s + 1].hi, WZ[ZRC + s + 1].lo, WZ[ZRC + s + 1].hi);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (s + 2 < ZRC && s + 2 < nzr) {
+                            dss_pair_loadx(XZ[1], xb + DSS_ZR_COL(s + 3 < ZRC ? s + 3 : 0) * 32);
+                            dss_pair_loadx(XR[1], xb + DSS_ZR_COL(ZRL + (s + 3 < ZRC ? s + 3 : 0)) * 32);
+                        }
                     }
                 }
                 if (recur_first) { az = gz + az; ar = gr + ar; }
                 if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
-                const f32x2 z = dss_sigmoid_pk(L.tansig, az), r = dss_sigmoid_pk(L.tansig, ar);
+                f32x2 z, r;
+                dss_sigmoid_pk2(L.tansig, az, ar, z, r);
                 f32x2 h = ahv * r + gh;
                 h = dss_tanh_pk(L.tansig, h);
                 st = z * st + (1 - z) * h;
                 *reinterpret_cast<f32x2 *>(&L.state_a[cur ^ 1][2 * unit]) = st;
                 if (STAMP) { asm volatile("" :: "v"(st)); unsigned long long t = __builtin_readcyclecounter(); sa[3] += t - ta; ta = t; }
+                if (!HAS_FC) __builtin_amdgcn_s_setprio(0);
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
                 DSS_PH_CHAIN(L.state_a[cur ^ 1])                     // next sample's h chain, under GRU B
@@ -474,15 +553,17 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
                 if constexpr (HAS_FC) {                                                 // sample_mdense, all nodes, both utterances
                     const float thr_a = L.thr[0][level], thr_b = L.thr[1][level];      // issued first, used last
                     f32x2 s0 = {fb0, fb0}, s1 = {fb1, fb1};                            // layer 0 / layer 1 sums of (A, B)
+                    PairX bj[NB / 4];                                                  // all of GRU B's state first: one LDS round trip
+#pragma unroll
+                    for (int j4 = 0; j4 < NB / 4; ++j4) dss_pair_loadx(bj[j4], reinterpret_cast<const char *>(&L.state_b[4 * j4][0]));
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j4 = 0; j4 < NB / 4; ++j4) {
-                        PairX bj;
-                        dss_pair_loadx(bj, reinterpret_cast<const char *>(&L.state_b[4 * j4][0]));
-                        f32x2 t0, t1, t2, t3;
-                        DSS_PK_FC4(s0, s1, t0, t1, t2, t3, bj.v[0], bj.v[1], bj.v[2], bj.v[3],
-                                   fw[4 * j4], fw[4 * j4 + 1], fw[4 * j4 + 2], fw[4 * j4 + 3]);
+                        f32x2 ft[8];
+                        DSS_PK_FC4(s0, s1, ft, bj[j4], fw[4 * j4], fw[4 * j4 + 1], fw[4 * j4 + 2], fw[4 * j4 + 3]);
                     }
-                    const f32x2 t1 = dss_tanh_pk(L.tansig, s0), t2 = dss_tanh_pk(L.tansig, s1);
+                    f32x2 t1, t2;
+                    dss_tanh_pk2(L.tansig, s0, s1, t1, t2);
                     f32x2 lg = ff0 * t1;
                     const f32x2 lg2 = ff1 * t2;
                     lg += lg2;

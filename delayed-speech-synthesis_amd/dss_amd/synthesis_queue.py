@@ -57,9 +57,26 @@ class AsynchronousSynthesisQueue:
             return
         # one ragged launch per MAX_BATCH files: every file gets a fresh decoder (training.py:193) and its own frame
         # count; rows are dispatched longest first so short files fill in behind long ones
+        def emit(name, wav):
+            try:
+                wavwrite(Path(name).with_suffix(".wav").as_posix(), 16000, wav)
+            except Exception as e:          # one unwritable path never stops the others (training.py:196-198)
+                logger.error(f"Could not synthesize {name} due to an unexpected exceptions: {str(e)}")
+
         for a in range(0, len(loaded), self.MAX_BATCH):
             chunk = loaded[a:a + self.MAX_BATCH]
-            frames = max(f.shape[0] for _, f in chunk)
-            pcm = LPCNetBatch(len(chunk), frames).synthesize_ragged([f for _, f in chunk])
+            try:
+                frames = max(f.shape[0] for _, f in chunk)
+                pcm = LPCNetBatch(len(chunk), frames).synthesize_ragged([f for _, f in chunk])
+            except Exception as e:
+                # the batched launch failed (allocation, device error): fall back to one launch per file so that
+                # every file that can be synthesised still is, and each failure names its file like the reference does
+                logger.error(f"Batched synthesis of {len(chunk)} files failed ({e}); retrying file by file.")
+                for name, f in chunk:
+                    try:
+                        emit(name, LPCNetBatch(1, f.shape[0]).synthesize(f[None])[0])
+                    except Exception as e1:
+                        logger.error(f"Could not synthesize {name} due to an unexpected exceptions: {str(e1)}")
+                continue
             for (name, _), wav in zip(chunk, pcm):
-                wavwrite(Path(name).with_suffix(".wav").as_posix(), 16000, wav)
+                emit(name, wav)

@@ -305,6 +305,24 @@ def test_teacher_forced_logits_match_the_oracle(oracle, model, generic):
     assert np.array_equal(pcm[0], m2)
 
 
+def test_teacher_forcing_refuses_another_shape(model):
+    """the forced excitation and the logit trace are sized for the shape given to force_excitation; a call of
+    any other shape (or a ragged one) while forcing is on must fail instead of indexing past them."""
+    from dss_amd import _lib
+    from dss_amd.lpcnet import LPCNetBatch
+    gpu = LPCNetBatch(3, 6)
+    gpu.enable_trace(1)
+    gpu.force_excitation(np.full((2, 4 * 160), 128, np.uint8), 4)
+    f = np.stack([synthetic_features(50 + b, 6) for b in range(3)])
+    with pytest.raises(_lib.DssError, match="teacher forcing was set up"):
+        gpu.synthesize(f)                                    # 3 x 6 against buffers for 2 x 4
+    with pytest.raises(_lib.DssError, match="teacher forcing was set up"):
+        gpu.synthesize_ragged([f[0, :4], f[1, :2]])
+    assert gpu.synthesize(f[:2, :4]).shape == (2, 640)       # the shape it was set up for still runs
+    gpu.force_excitation(None, 4)
+    assert gpu.synthesize(f).shape == (3, 960)
+
+
 def test_gru_a_recurrent_first_order_flag(oracle):
     """dss_blob_header.gru_a_order = 1 (xiph nnet.c 2019-20 association): both kernels follow the oracle bit for bit,
     and the teacher-forced states differ from the default order's in the last bits only."""

@@ -146,6 +146,23 @@ def test_asynchronous_synthesis_queue_file_contract(tmp_path, oracle):
         rate, pcm = wavread(tmp_path / f"{name}.wav")
         assert rate == 16000 and np.array_equal(pcm, oracle.lpcnet_utterance(m, synthetic_features(ord(name), n)))
     assert not (tmp_path / "bad.wav").exists()
+    # a failing batched launch (here: made to fail) falls back to one launch per file, and an unwritable output path
+    # costs only its own file (local/training.py:189-198 wraps load, synthesis and write per file)
+    from dss_amd import lpcnet as lp
+    for name in lengths:
+        (tmp_path / f"{name}.wav").unlink()
+    (tmp_path / "b.wav").mkdir()                       # wavwrite to a directory fails
+    real = lp.LPCNetBatch.synthesize_ragged
+    lp.LPCNetBatch.synthesize_ragged = lambda self, *a, **k: (_ for _ in ()).throw(RuntimeError("injected"))
+    try:
+        for name in lengths:
+            q.add_job(str(tmp_path / f"{name}.npy"))
+        q.wait()
+    finally:
+        lp.LPCNetBatch.synthesize_ragged = real
+    for name in ("a", "c"):
+        rate, pcm = wavread(tmp_path / f"{name}.wav")
+        assert np.array_equal(pcm, oracle.lpcnet_utterance(m, synthetic_features(ord(name), lengths[name])))
 
 
 def test_replay_of_a_recorded_session(tmp_path, oracle):
