@@ -12,7 +12,7 @@ import json
 import sys
 from collections import defaultdict
 
-DOMINANT = "lpcnet_sample_kernel"
+DOMINANT = "lpcnet_sample"
 
 
 def per_kernel(path, counter):
