@@ -151,16 +151,23 @@ def main():
     lpcnet.load_model(synthetic=True)           # seeded synthetic weights, explicitly (no checkpoint can be fetched offline)
     feats = torch.from_numpy(np.stack([synthetic_features(rank * B + b, FRAMES) for b in range(B)])).cuda()
     out = torch.empty((B, FRAMES * FRAME), dtype=torch.int16, device="cuda")
-    wire = out.view(torch.uint8)                # RCCL has no int16 type: the PCM shard travels as bytes
-    gathered = [torch.empty_like(wire) for _ in range(world)] if (world > 1 and rank == 0) else None
     dec = lpcnet.LPCNetBatch(B, FRAMES, device=local_rank)
     info = lpcnet.model_info()
+    cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+
+    def kernel_for(n_utts):     # the library's own rule (csrc/lpcnet_sample.hip dss_launch_sample_network)
+        pair = info["fast_path"] == 1 and info["h_lds_bytes"] <= 131840 and n_utts > max(128, cus)
+        return "lpcnet_sample_pair_kernel (two utterances per workgroup)" if pair else info["kernel"]
+    from dss_amd.distributed import gather_pcm     # the collective the world-size-2 gloo test covers (tests/test_cpu_distributed.py)
+    gathered_rows = [0]
 
     def step():
         dec.reset_async()
         dec.synthesize_torch(feats, out=out)
         if world > 1:
-            dist.gather(wire, gathered, dst=0)
+            full = gather_pcm(out, world * B, dst=0)            # int16 shards as bytes, one RCCL gather, rank order
+            if full is not None:
+                gathered_rows[0] = int(full.shape[0])
 
     def fence():
         if world > 1:
@@ -206,6 +213,56 @@ def main():
                    "slots, over 64 h blocks, or an LDS image over 138752 B); dss_lpcnet_model_info reports it, "
                    "profiles/r2_model_fit.txt has the steps in between"}
 
+    # BASELINE.json configs[3], one GPU's share: 1024 utterances in one call (two utterances per workgroup beyond one per CU)
+    config4 = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        B4 = 1024
+        f4 = torch.from_numpy(np.stack([synthetic_features(b, FRAMES) for b in range(B4)])).cuda()
+        o4 = torch.empty((B4, FRAMES * FRAME), dtype=torch.int16, device="cuda")
+        d4 = lpcnet.LPCNetBatch(B4, FRAMES, device=local_rank)
+
+        def step4():
+            d4.reset_async()
+            d4.synthesize_torch(f4, out=o4)
+        step4(); torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for _ in range(3):
+            step4()
+        torch.cuda.synchronize()
+        t4 = (time.perf_counter() - t4) / 3
+        d4.enable_timing(True)
+        for _ in range(3):
+            step4()
+        torch.cuda.synchronize()
+        k4 = d4.kernel_ms(0)
+        d4.enable_timing(False)
+        config4 = {"workload": "configs[3] per-GPU share: 1024 synthetic 1-s utterances, one call, fresh decoders, features in HBM",
+                   "ms_per_step": t4 * 1e3, "value": B4 * FRAMES * FRAME / t4, "unit": "samples/s", "x_realtime": B4 * FRAMES * FRAME / t4 / 16000.0,
+                   "kernel": kernel_for(B4),
+                   "kernel_ms": k4, "kernel_ms_source": "HIP events on the launch stream"}
+        del d4, f4, o4
+
+    # BASELINE.json configs[2]: 64 segments of 64-channel ECoG (1.04 s) -> HGA -> z-score -> BiLSTM -> LPCNet -> PCM
+    config3 = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        from dss_amd.pipeline import SegmentPipeline
+        from dss_amd.synthetic import synthetic_ecog
+        B3 = 64
+        ecog = torch.from_numpy(np.stack([synthetic_ecog(1000 + b, 1040, 64) for b in range(B3)])).cuda()
+        pipe = SegmentPipeline(B3)
+        pipe(ecog); torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(3):
+            pcm3 = pipe(ecog)
+        torch.cuda.synchronize()
+        t3 = (time.perf_counter() - t3) / 3
+        config3 = {"workload": "configs[2]: 64 segments x 1.04 s x 64-ch synthetic ECoG @1 kHz -> HGA (fused kernel) -> z-score -> "
+                               "BiLSTM (PyTorch-ROCm, seeded weights) -> LPCNet -> int16 PCM, fresh extractor and decoder per segment",
+                   "ms_per_step": t3 * 1e3, "audio_seconds": float(pcm3.shape[0] * pcm3.shape[1] / 16000.0),
+                   "x_realtime": float(pcm3.shape[0] * pcm3.shape[1] / 16000.0 / t3),
+                   "note": "64 workgroups on 256 CUs: bounded by the single-utterance speed of the sample-rate kernel, not by HGA or the BiLSTM"}
+        del pipe
+
     # second half of BASELINE.json's metric: ECoG -> audio latency of the streaming mode (config 5), N=1 only
     latency = None
     if rank == 0 and world == 1 and not args.no_latency:
@@ -224,7 +281,7 @@ def main():
     # process, so they come from the committed rocprofv3 --pmc passes of this same command (profiles/), and are quoted
     # only for the workload they were taken on
     traffic, counters = None, None
-    tag = {256: "r2_b256", 1024: "r2_b1024"}.get(B)
+    tag = {256: "r3_b256", 1024: "r3_b1024"}.get(B)
     try:
         with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
             traffic = float(json.load(f)["hbm_bytes_per_launch_corrected"]) / 1e9          # GB per launch
@@ -252,7 +309,7 @@ def main():
             "bound": "valu",                 # fp32 vector ALU without FMA; the kernel's real ceiling
             "achieved": achieved_tf, "peak": FP32_NOFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved_tf / FP32_NOFMA_PEAK_TF,
             "traffic": traffic, "traffic_unit": "GB of HBM per launch (PMC, profiles/)",
-            "kernel": info["kernel"], "kernel_ms": k_ms, "frame_kernels_ms": f_ms,
+            "kernel": kernel_for(B), "kernel_ms": k_ms, "frame_kernels_ms": f_ms,
             "algorithmic_flops_per_sample": flops_per_sample, "samples_per_launch": synth,
             "frac_of_fma_peak": achieved_tf / FP32_VECTOR_PEAK_TF,
             "note": "useful fp32 operations (SURVEY 8d algorithmic flops) per second of the sample-rate kernel, against the "
@@ -263,7 +320,7 @@ def main():
         if counters:
             c = counters.get("derived", {})
             roofline["valu_issue_utilisation"] = c.get("valu_issue_utilisation")
-            roofline["counters_from"] = f"profiles/{tag}_pmc_issue.json"
+            roofline["counters_from"] = f"profiles/{tag}_pmc_issue.json @ git {counters.get('git_sha', 'unknown')}"
         hbm = {"bound": "hbm", "achieved": hbm_equiv, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_equiv / HBM_PEAK_GBS,
                "algorithmic_bytes_per_sample": bps, "algorithmic_GB_per_launch": alg_bytes_per_launch / 1e9,
                "hbm_traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / HBM_PEAK_GBS) if traffic else None,
@@ -282,11 +339,13 @@ def main():
                        "batch_per_gpu": B, "frames": FRAMES, "weights": "synthetic seed 0 (xiph weights unobtainable offline)",
                        "parallelism": f"utterance-sharded x{world}",
                        "world_size": (dist.get_world_size() if world > 1 else 1),
-                       "gathered_bytes_per_step": (int(world * wire.numel()) if world > 1 else 0)},
+                       "gathered_bytes_per_step": (int(gathered_rows[0]) * FRAMES * FRAME * 2 if world > 1 else 0)},
             "x_realtime": value / 16000.0, "samples_per_s_per_gpu": value / world,
             "roofline": roofline,
             "roofline_hbm_equiv": hbm,
             "generic_kernel": generic,
+            "config4_per_gpu": config4,
+            "config3": config3,
             "cpu_baseline": cpu,
             "latency": latency,
         }

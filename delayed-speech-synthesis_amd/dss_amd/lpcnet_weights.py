@@ -154,7 +154,8 @@ def make_synthetic_weights(seed: int = 0, dims: LPCNetDims = LPCNetDims(),
     return w
 
 
-def pack_blob(w: Dict[str, np.ndarray], dims: LPCNetDims = LPCNetDims(), gru_a_order: int = GRUA_INPUT_FIRST) -> bytes:
+def pack_blob(w: Dict[str, np.ndarray], dims: LPCNetDims = LPCNetDims(), gru_a_order: int = GRUA_INPUT_FIRST,
+              source_branches: int = 0) -> bytes:
     d = dims
     if gru_a_order not in (GRUA_INPUT_FIRST, GRUA_RECUR_FIRST):
         raise ValueError("gru_a_order must be 0 (input first, xiph 2021) or 1 (recurrent first, xiph 2019-2020)")
@@ -163,7 +164,8 @@ def pack_blob(w: Dict[str, np.ndarray], dims: LPCNetDims = LPCNetDims(), gru_a_o
     shapes = _shapes(d, nblocks, idx_len)
     header = struct.pack(
         "<8s22i", MAGIC, 1, d.nb_features, d.nb_bands, d.embed_pitch_dim, d.pitch_max, d.conv1_out, d.conv2_out,
-        d.dense1_out, d.dense2_out, d.gru_a, d.gru_b, d.dual_fc_out, d.lpc_order, nblocks, idx_len, int(gru_a_order), 0, 0, 0, 0, 0, 0)
+        d.dense1_out, d.dense2_out, d.gru_a, d.gru_b, d.dual_fc_out, d.lpc_order, nblocks, idx_len, int(gru_a_order),
+        int(source_branches), 0, 0, 0, 0, 0)
     assert len(header) == 96
     parts = [header]
     for name in _SECTIONS:
@@ -175,6 +177,12 @@ def pack_blob(w: Dict[str, np.ndarray], dims: LPCNetDims = LPCNetDims(), gru_a_o
             raise ValueError(f"{name}: dtype {a.dtype} != {want}")
         parts.append(a.tobytes())
     return b"".join(parts)
+
+
+def blob_source_branches(blob: bytes) -> int:
+    """dss_blob_header.source_branches: 0 unknown (synthetic / older blobs), bit 0 float branch, bit 1 DOT_PROD branch present
+    in the nnet_data.c the blob was converted from."""
+    return int(struct.unpack_from("<i", blob, 8 + 4 * 16)[0])
 
 
 def unpack_blob(blob: bytes):

@@ -12,8 +12,18 @@ runs once::
 published sources; every array is checked for its exact size against the architecture constants, so a different
 revision fails loudly instead of producing a wrong model.  A name that differs can be remapped with ``names={...}``.
 What is tested here (tests/test_cpu_nnet_data.py) is the parser and the mapping on a synthetic file written in the same
-C syntax, including the ``#ifdef DOT_PROD`` / ``#else`` pairs xiph emits for quantisable layers (the ``#else`` branch,
-i.e. the float weights of the generic build, is the one taken -- the build the reference effectively uses).
+C syntax, including the ``#ifdef DOT_PROD`` / ``#else`` pairs xiph emits for quantisable layers.
+
+**Which arithmetic does the reference's build use?  Unverifiable here, so BOTH branches are kept.**  The blob (what the
+kernels and the oracle run on) is built from the ``#else`` branch: float weights, the generic ``vec.h`` path, which is
+what a plain ``-O2`` x86-64 build selects in the xiph revisions this was written from (no ``-mavx*`` reaches the compiler,
+extensions/lpcnet/setup.py:27-29,48-52).  Later public revisions select ``vec_avx.h`` whenever ``__SSE2__`` is defined
+(every x86-64 build) and define ``DOT_PROD`` there: int8 ``qweight`` blocks, a quantised GRU input, ``subias`` and
+vectorised exp-based activations -- a different arithmetic.  The converter therefore also keeps the ``#ifdef DOT_PROD``
+branch's arrays (int8 weights and every array that exists only there: scales, ``subias``) in a side file next to the blob
+(``<out>.dotprod.npz``) and records in the blob header (``source_branches``) which branches the source had.  No kernel
+reads the side file: whether one has to is decided by the first xiph-produced vector (tests/golden/README.md), whose
+recipe stores the build's predefined macros beside it.
 
 Layout facts relied on (xiph src/nnet.c, generic path):
   * DenseLayer / conv1d ``input_weights``: input-major, ``w[i * nb_neurons + j]`` (sgemv_accum with stride = outputs);
@@ -58,13 +68,19 @@ _ARRAY = re.compile(r"(?:static\s+)?const\s+(float|int|qweight|opus_int8|signed\
                     re.S)
 
 
-def _strip_dot_prod(text: str) -> str:
-    """Keep the ``#else`` (float) branch of every ``#ifdef DOT_PROD`` block and drop other preprocessor lines."""
-    out, stack = [], []            # stack of [is_dot_prod_block, currently_in_else]
+BRANCH_FLOAT, BRANCH_DOT_PROD = 1, 2          # bits of dss_blob_header.source_branches
+
+
+def _select_branch(text: str, dot_prod: bool):
+    """Resolve every ``#ifdef DOT_PROD`` / ``#else`` / ``#endif`` block to one branch (``dot_prod``: the ``#ifdef`` side,
+    else the ``#else`` side) and drop other preprocessor lines.  Returns (text, number of DOT_PROD blocks seen)."""
+    out, stack, n_blocks = [], [], 0            # stack of [is_dot_prod_block, currently_in_else]
     for line in text.splitlines():
         t = line.strip()
         if t.startswith("#if"):
-            stack.append([bool(re.match(r"#\s*ifdef\s+DOT_PROD\b", t)), False])
+            is_dp = bool(re.match(r"#\s*ifdef\s+DOT_PROD\b", t))
+            n_blocks += is_dp
+            stack.append([is_dp, False])
             continue
         if t.startswith("#else"):
             if stack:
@@ -76,25 +92,57 @@ def _strip_dot_prod(text: str) -> str:
             continue
         if t.startswith("#"):
             continue
-        if any(is_dp and not in_else for is_dp, in_else in stack):
-            continue                # quantised (int8) variant: not the generic build
+        if any(is_dp and (in_else == dot_prod) for is_dp, in_else in stack):
+            continue                # the other branch
         out.append(line)
-    return "\n".join(out)
+    return "\n".join(out), n_blocks
 
 
-def parse_c_arrays(text: str) -> Dict[str, np.ndarray]:
-    """All ``const float/int NAME[...] = {...};`` initialisers of a C file -> {name: 1-D array}."""
-    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
-    text = re.sub(r"//[^\n]*", " ", text)
-    text = _strip_dot_prod(text)
+def _strip_dot_prod(text: str) -> str:
+    """Keep the ``#else`` (float) branch of every ``#ifdef DOT_PROD`` block and drop other preprocessor lines."""
+    return _select_branch(text, dot_prod=False)[0]
+
+
+_INT_TOKEN = re.compile(r"^[+-]?(0[xX][0-9a-fA-F]+|\d+)$")
+
+
+def _parse_resolved(text: str) -> Dict[str, np.ndarray]:
     arrays: Dict[str, np.ndarray] = {}
     for ctype, name, body in _ARRAY.findall(text):
         toks = [t for t in re.split(r"[\s,]+", body.strip()) if t]
         if ctype == "int":
             arrays[name] = np.array([int(t, 0) for t in toks], dtype=np.int32)
+        elif ctype != "float" and toks and all(_INT_TOKEN.match(t) for t in toks):
+            arrays[name] = np.array([int(t, 0) for t in toks], dtype=np.int8)      # qweight / opus_int8 under DOT_PROD
         else:
             arrays[name] = np.array([float(t.rstrip("fF")) for t in toks], dtype=np.float32)
     return arrays
+
+
+def _uncomment(text: str) -> str:
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def parse_c_arrays(text: str) -> Dict[str, np.ndarray]:
+    """All ``const float/int NAME[...] = {...};`` initialisers of a C file -> {name: 1-D array}, ``#else`` (float) branch
+    of the ``#ifdef DOT_PROD`` pairs."""
+    return _parse_resolved(_strip_dot_prod(_uncomment(text)))
+
+
+def parse_c_arrays_both(text: str):
+    """Both resolutions of the ``#ifdef DOT_PROD`` pairs: (float-branch arrays, DOT_PROD-only arrays, branches).
+    The second dict holds every array of the ``#ifdef`` side that is absent from or different in the ``#else`` side: the
+    int8 weight arrays (same names as their float counterparts) and whatever exists only under DOT_PROD (scales,
+    ``subias``).  ``branches``: BRANCH_FLOAT | BRANCH_DOT_PROD when the file has such pairs, BRANCH_FLOAT otherwise."""
+    text = _uncomment(text)
+    ftext, n_blocks = _select_branch(text, dot_prod=False)
+    fl = _parse_resolved(ftext)
+    if not n_blocks:
+        return fl, {}, BRANCH_FLOAT
+    dp_all = _parse_resolved(_select_branch(text, dot_prod=True)[0])
+    dp = {k: v for k, v in dp_all.items() if k not in fl or v.dtype != fl[k].dtype or v.size != fl[k].size or not np.array_equal(v, fl[k])}
+    return fl, dp, BRANCH_FLOAT | BRANCH_DOT_PROD
 
 
 def weights_from_nnet_data(text: str, dims: LPCNetDims = LPCNetDims(), names: Optional[Dict[str, str]] = None):
@@ -102,7 +150,7 @@ def weights_from_nnet_data(text: str, dims: LPCNetDims = LPCNetDims(), names: Op
     mismatch."""
     nm = dict(DEFAULT_NAMES)
     nm.update(names or {})
-    arrays = parse_c_arrays(text)
+    arrays = parse_c_arrays(text)               # the #else (float) branch: the arithmetic the kernels implement
     d = dims
     fin = d.nb_features + d.embed_pitch_dim
     na, nb = d.gru_a, d.gru_b
@@ -158,12 +206,18 @@ def weights_from_nnet_data(text: str, dims: LPCNetDims = LPCNetDims(), names: Op
 
 def convert(path_in: str, path_out: str, names: Optional[Dict[str, str]] = None, gru_a_order: int = 0) -> int:
     """gru_a_order: which association order of compute_sparse_gru's z/r pre-activation the xiph revision the weights
-    came with uses (include/dss_lpcnet_blob.h): 0 = input before the blocks (nnet.c 2021), 1 = blocks first (2019-20)."""
+    came with uses (include/dss_lpcnet_blob.h): 0 = input before the blocks (nnet.c 2021), 1 = blocks first (2019-20).
+    Writes the blob and, when the source has ``#ifdef DOT_PROD`` branches, ``<path_out>.dotprod.npz`` with that side's
+    arrays (int8 weights, scales, subias): kept for the day a xiph vector says the reference's build uses them."""
     with open(path_in, "r", errors="replace") as f:
-        w = weights_from_nnet_data(f.read(), names=names)
-    blob = pack_blob(w, gru_a_order=gru_a_order)
+        text = f.read()
+    w = weights_from_nnet_data(text, names=names)
+    _, dp, branches = parse_c_arrays_both(text)
+    blob = pack_blob(w, gru_a_order=gru_a_order, source_branches=branches)
     with open(path_out, "wb") as f:
         f.write(blob)
+    if dp:
+        np.savez(path_out + ".dotprod.npz", **dp)
     return len(blob)
 
 
@@ -187,6 +241,12 @@ if __name__ == "__main__":
         sys.exit("usage: python -m dss_amd.nnet_data <nnet_data.c> <out.blob> [gru_a_order: 0 (default, xiph 2021) | 1 (2019-20)]")
     n = convert(sys.argv[1], sys.argv[2], gru_a_order=int(sys.argv[3]) if len(sys.argv) == 4 else 0)
     print(f"wrote {sys.argv[2]}: {n} bytes")
+    from .lpcnet_weights import blob_source_branches
+    with open(sys.argv[2], "rb") as f:
+        br = blob_source_branches(f.read(96))
+    print("source branches: " + {1: "float only (no #ifdef DOT_PROD pairs)", 3: "float AND DOT_PROD (int8) -- the blob holds the float "
+          "branch, the DOT_PROD arrays are in " + sys.argv[2] + ".dotprod.npz; check which one the reference's build compiles "
+          "(gcc -dM -E on its vec.h: DOT_PROD defined?) before trusting parity"}.get(br, str(br)))
     try:
         with open(sys.argv[2], "rb") as f:
             fit = kernel_fit(f.read())

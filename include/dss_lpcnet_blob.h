@@ -65,8 +65,16 @@ typedef struct dss_blob_header {
                                *                             (zrh = input; recur = bias + diag*state + sparse; zrh += recur)
                                * The h gate is the same in both (r*recur_h + input_h; a float add commutes).  Blobs written
                                * before this field existed have 0 here. */
-    int32_t reserved[6];
+    int32_t source_branches;  /* which sides of nnet_data.c's `#ifdef DOT_PROD` pairs the source had: bit 0 the `#else` side
+                               * (float weights, generic vec.h -- what this blob holds and the kernels compute), bit 1 the
+                               * `#ifdef` side (int8 qweight blocks, scales, subias: vec_avx.h / vec_neon.h builds; kept by
+                               * the converter in <blob>.dotprod.npz, read by no kernel).  0 = unknown (synthetic models,
+                               * blobs written before this field existed).  Informational: see DESIGN.md 2. */
+    int32_t reserved[5];
 } dss_blob_header;            /* 96 bytes */
+
+#define DSS_BLOB_BRANCH_FLOAT 1
+#define DSS_BLOB_BRANCH_DOT_PROD 2
 
 #define DSS_GRUA_INPUT_FIRST 0
 #define DSS_GRUA_RECUR_FIRST 1

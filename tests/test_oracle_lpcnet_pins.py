@@ -425,6 +425,11 @@ XIPH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lpcne
                     "nnet_data.c are absent from the reference tree (see tests/golden/README.md for how to make it)")
 def test_oracle_against_real_xiph_vectors(oracle):
     g = np.load(XIPH)
+    if "predefined_macros" in g.files:      # tests/golden/README.md: the xiph build's `gcc -dM -E` output travels with the vector
+        macros = str(g["predefined_macros"])
+        assert "DOT_PROD" not in macros, ("this vector comes from a build that compiles nnet.c's DOT_PROD (int8 qweight, "
+                                          "subias) path -- a different arithmetic from the float path the oracle and the "
+                                          "kernels implement (DESIGN.md 2); the int8 arrays are in <blob>.dotprod.npz")
     m = oracle.lpcnet_model(g["blob"].tobytes())
     got = oracle.lpcnet_utterance(m, g["features"][:, :20]).astype(np.int32)
     assert np.max(np.abs(got - g["pcm"].astype(np.int32))) <= 1           # north_star: +-1 LSB on 16-bit PCM

@@ -10,6 +10,7 @@ Derived: wave-instructions per sample and workgroup, cycles per sample, and the 
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -29,7 +30,7 @@ def main():
     samples = batch * 98 * 160
     wgs = batch / utts_per_wg
     cycles = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0            # the counter sums the 8 XCDs
-    doc = {"command": cmd, "kernel": name, "workload": f"batch {batch} x 1-s utterances (98 synthesised frames each)",
+    doc = {"git_sha": os.environ.get("DSS_PROFILE_SHA", "unknown"), "command": cmd, "kernel": name, "workload": f"batch {batch} x 1-s utterances (98 synthesised frames each)",
            "samples_per_launch": samples, "counters_per_launch": c,
            "per_sample_per_utterance": {
                "valu_wave_instructions": c.get("SQ_INSTS_VALU", 0) / samples,

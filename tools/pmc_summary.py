@@ -9,6 +9,7 @@ KB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, WRITE_SIZE is
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -31,6 +32,7 @@ def main():
     name = next(k for k in fetch if DOMINANT in k)
     f_kb, w_kb = fetch[name]["mean_KB"], write[name]["mean_KB"]
     doc = {
+        "git_sha": os.environ.get("DSS_PROFILE_SHA", "unknown"),
         "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
                    "--warmup 1 --no-cpu-baseline --no-latency",
         "kernel": name,

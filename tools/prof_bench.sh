@@ -1,8 +1,8 @@
 #!/usr/bin/env bash
 # Profiles of bench.py for profiles/<tag>_*: kernel-trace stats, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and
-# SQ issue counters.   gpurun -- 'bash tools/prof_bench.sh r2 256'
+# SQ issue counters.   gpurun -- "bash tools/prof_bench.sh r3 256 1 $(git rev-parse --short HEAD)"   (the box has no .git)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r3}; B=${2:-256}; UPW=${3:-1}      # UPW: utterances per workgroup of the kernel that serves batch B (2 beyond one per CU)
+TAG=${1:-r3}; B=${2:-256}; UPW=${3:-1}; export DSS_PROFILE_SHA=${4:-unknown}      # UPW: utterances per workgroup of the kernel that serves batch B (2 beyond one per CU)
 O=$R/gpurun_out/prof_${TAG}_b$B; mkdir -p $O
 ARGS="--batch $B --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
 cd /tmp && export TMPDIR=/tmp
