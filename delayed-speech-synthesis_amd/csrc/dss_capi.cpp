@@ -996,7 +996,18 @@ extern "C" int dss_lpcnet_batch_tap(dss_lpcnet_batch *b, int utt, int which, flo
 // ------------------------------------------------------------------------------------------------------
 // xiph drop-in symbols: one state = a batch of one utterance, one frame per call
 // ------------------------------------------------------------------------------------------------------
-struct LPCNetState { dss_lpcnet_batch *b; };
+// One frame per call is a fixed sequence of ten small launches between two tiny copies (what an unchanged decode_online.py
+// pays per 10 ms, local/units.py:531-538).  From its second call on, a state replays that sequence from a HIP graph captured
+// once on a stream of its own: pinned staging for the 80 bytes in and the 320 bytes out, one hipGraphLaunch, one wait.
+struct LPCNetState {
+    dss_lpcnet_batch *b;
+    hipStream_t stream = nullptr;
+    hipGraphExec_t exec = nullptr;
+    float *h_feat = nullptr;          // pinned
+    short *h_pcm = nullptr;           // pinned
+    long calls = 0;
+    int graph_off = 0;                // capture failed once (or DSS_LEVEL1_EAGER is set): eager launches from then on
+};
 
 extern "C" LPCNetState *lpcnet_create(void)
 {
@@ -1004,20 +1015,63 @@ extern "C" LPCNetState *lpcnet_create(void)
     if (!b) return nullptr;
     LPCNetState *st = new LPCNetState;
     st->b = b;
+    st->graph_off = getenv("DSS_LEVEL1_EAGER") != nullptr;
     return st;
 }
 
 extern "C" int lpcnet_init(LPCNetState *st)
 {
     if (!st) return -1;
+    if (st->stream) hipStreamSynchronize(st->stream);
     return dss_lpcnet_batch_reset(st->b, -1);
 }
 
 extern "C" void lpcnet_destroy(LPCNetState *st)
 {
     if (!st) return;
+    hipSetDevice(st->b->device);
+    if (st->stream) hipStreamSynchronize(st->stream);
+    if (st->exec) hipGraphExecDestroy(st->exec);
+    if (st->stream) hipStreamDestroy(st->stream);
+    if (st->h_feat) hipHostFree(st->h_feat);
+    if (st->h_pcm) hipHostFree(st->h_pcm);
     dss_lpcnet_batch_destroy(st->b);
     delete st;
+}
+
+// one frame through the captured graph; DSS_OK, or an error after which the caller falls back to the eager path for good
+static int level1_graph_frame(LPCNetState *st, const float *features, short *output)
+{
+    dss_lpcnet_batch *b = st->b;
+    DSS_HIP_CHECK(hipSetDevice(b->device));
+    if (!st->stream) {
+        DSS_HIP_CHECK(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+        DSS_HIP_CHECK(hipHostMalloc((void **)&st->h_feat, DSS_NB_FEATURES * sizeof(float), hipHostMallocDefault));
+        DSS_HIP_CHECK(hipHostMalloc((void **)&st->h_pcm, DSS_FRAME_SIZE * sizeof(short), hipHostMallocDefault));
+    }
+    memcpy(st->h_feat, features, DSS_NB_FEATURES * sizeof(float));
+    if (!st->exec) {
+        hipGraph_t graph = nullptr;
+        DSS_HIP_CHECK(hipStreamBeginCapture(st->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e1 = hipMemcpyAsync(b->d_feat, st->h_feat, DSS_NB_FEATURES * sizeof(float), hipMemcpyHostToDevice, st->stream);
+        b->d.slot_of = nullptr; b->d.count_of = nullptr;
+        const int rc = e1 == hipSuccess ? run_batch(b, b->d_feat, 1, 1, DSS_NB_FEATURES, b->d_pcm, st->stream) : DSS_ENODEV;
+        hipError_t e2 = hipMemcpyAsync(st->h_pcm, b->d_pcm, DSS_FRAME_SIZE * sizeof(short), hipMemcpyDeviceToHost, st->stream);
+        hipError_t e3 = hipStreamEndCapture(st->stream, &graph);             // always ends the capture
+        if (rc || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || !graph) {
+            if (graph) hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            dss_set_error("level-1 graph capture failed; staying on eager launches");
+            return DSS_ENODEV;
+        }
+        hipError_t e4 = hipGraphInstantiate(&st->exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e4 != hipSuccess) { st->exec = nullptr; dss_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e4)); return DSS_ENODEV; }
+    }
+    DSS_HIP_CHECK(hipGraphLaunch(st->exec, st->stream));
+    DSS_HIP_CHECK(hipStreamSynchronize(st->stream));
+    memcpy(output, st->h_pcm, DSS_FRAME_SIZE * sizeof(short));
+    return DSS_OK;
 }
 
 // The xiph ABI gives this call no error channel (void; cLPCNet.pxd:13) and its caller is a live prosthesis loop
@@ -1041,6 +1095,11 @@ extern "C" void lpcnet_synthesize(LPCNetState *st, const float *features, short 
         dss_set_error("lpcnet_synthesize: N must be %d, got %d", DSS_FRAME_SIZE, N);
         synth_failed(output, N);
         return;
+    }
+    // first call of a state: eager (it also sets the kernels' attributes); traced or timed states stay eager
+    if (st->calls++ > 0 && !st->graph_off && !st->b->trace && !st->b->timing) {
+        if (level1_graph_frame(st, features, output) == DSS_OK) return;
+        st->graph_off = 1;               // nothing was enqueued by a failed capture: run this frame eagerly
     }
     if (dss_lpcnet_batch_synthesize(st->b, features, 1, 1, DSS_NB_FEATURES, output)) synth_failed(output, N);
 }
