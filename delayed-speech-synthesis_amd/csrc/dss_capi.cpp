@@ -1290,6 +1290,8 @@ struct dss_hga {
     double *d_zi0[2] = {nullptr, nullptr};
     double *d_in = nullptr, *d_out = nullptr;
     size_t in_cap = 0, out_cap = 0;
+    double *d_zs[2] = {nullptr, nullptr};                  // z-score mean / std on the device ...
+    std::vector<double> zs_host[2];                        // ... and on the host (host-buffer entry points)
 };
 
 static int hga_grow_rows(dss_hga *h, int need_rows)
@@ -1344,7 +1346,7 @@ extern "C" void dss_hga_destroy(dss_hga *h)
     if (!h) return;
     hipSetDevice(h->device);
     void *ptrs[] = {h->d.zi, h->d.rows, h->d_zi0[0], h->d_zi0[1], h->d_in, h->d_out, h->d_src_col, h->d_grid_of,
-                    h->d_comp_cols, h->d_comp_off, h->d_pre, h->d_raw};
+                    h->d_comp_cols, h->d_comp_off, h->d_pre, h->d_raw, h->d_zs[0], h->d_zs[1]};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
 }
@@ -1378,21 +1380,70 @@ extern "C" int dss_hga_frames_for(const dss_hga *h, int n)
     return W < 0 ? 0 : W;
 }
 
-extern "C" int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, int apply_log, void *hip_stream)
+// one call of the extractor on device-resident input: (S, n, C) rows, or with `fe` the raw amplifier rows
+static int hga_run(dss_hga *h, const double *d_data, const DssHgaFrontDev *fe, int n, double *d_out, int apply_log, hipStream_t s)
 {
-    if (!h || !d_data || !d_out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
-    DSS_HIP_CHECK(hipSetDevice(h->device));
     int row0, zr, rows;
     hga_plan(h, n, &row0, &zr, &rows);
     int rc = hga_grow_rows(h, rows);
     if (rc) return rc;
     int W = dss_hga_num_windows(rows, h->d.fs, h->d.wl, h->d.ws);
     if (W < 0) W = 0;
-    rc = dss_launch_hga(h->d, d_data, n, row0, zr, rows, W, d_out, apply_log, (hipStream_t)hip_stream);
+    rc = dss_launch_hga(h->d, d_data, fe, n, row0, zr, rows, W, d_out, apply_log, s);
     if (rc) return rc;
     h->first_frame = 0;
     return W;
 }
+
+extern "C" int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, int apply_log, void *hip_stream)
+{
+    if (!h || !d_data || !d_out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    return hga_run(h, d_data, nullptr, n, d_out, apply_log, (hipStream_t)hip_stream);
+}
+
+/* Optional z-score of the frames, (x - mean[c]) / std[c] (ZScoreNormalization, local/common.py:367-376; the last step of
+ * the reference's feature chain, decode_online.py:88-97), inside the extractor's launch.  NULL clears it.  The
+ * host-buffer entry points apply it on the host after their host-libm log (same two IEEE operations). */
+extern "C" int dss_hga_set_zscore(dss_hga *h, const double *means, const double *stds)
+{
+    if (!h || (!means) != (!stds)) { dss_set_error("z-score needs both means and stds (or neither)"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    for (int k = 0; k < 2; ++k) { if (h->d_zs[k]) hipFree(h->d_zs[k]); h->d_zs[k] = nullptr; h->zs_host[k].clear(); }
+    h->d.zs_mean = h->d.zs_std = nullptr;
+    if (!means) return DSS_OK;
+    if (dev_upload<double>(means, h->d.C, &h->d_zs[0]) || dev_upload<double>(stds, h->d.C, &h->d_zs[1])) return DSS_ENOMEM;
+    h->zs_host[0].assign(means, means + h->d.C);
+    h->zs_host[1].assign(stds, stds + h->d.C);
+    h->d.zs_mean = h->d_zs[0]; h->d.zs_std = h->d_zs[1];
+    return DSS_OK;
+}
+
+/* Tests and A/B timing only: 0 = choose (default: hga_fused_kernel, three launches when its ring does not fit),
+ * 1 = hga_fused_kernel, 2 = the three-launch form, 3 = hga_stream_kernel (one launch also for raw packets). */
+extern "C" int dss_selftest_hga_force_path(dss_hga *h, int path)
+{
+    if (!h || path < 0 || path > 3) return DSS_EINVAL;
+    h->d.force_path = path;
+    return DSS_OK;
+}
+
+// host-side finish of the host-buffer entry points: glibc log (pyx:46; DESIGN.md "HGA log"), then the optional z-score
+static void hga_host_finish(const dss_hga *h, double *out, size_t cnt)
+{
+    for (size_t k = 0; k < cnt; ++k) out[k] = log(out[k]);
+    if (!h->zs_host[0].empty()) {
+        const int C = h->d.C;
+        for (size_t k = 0; k < cnt; ++k) out[k] = (out[k] - h->zs_host[0][k % C]) / h->zs_host[1][k % C];
+    }
+}
+
+// the host-buffer entry points take the mean power from the device WITHOUT log and z-score (both are applied on the host)
+struct HgaNoZs {
+    dss_hga *h; const double *m, *sd;
+    explicit HgaNoZs(dss_hga *hh) : h(hh), m(hh->d.zs_mean), sd(hh->d.zs_std) { h->d.zs_mean = h->d.zs_std = nullptr; }
+    ~HgaNoZs() { h->d.zs_mean = m; h->d.zs_std = sd; }
+};
 
 extern "C" int dss_hga_extract(dss_hga *h, const double *data, int n, double *out)
 {
@@ -1404,12 +1455,13 @@ extern "C" int dss_hga_extract(dss_hga *h, const double *data, int n, double *ou
     if (in_n > h->in_cap) { if (h->d_in) hipFree(h->d_in); DSS_HIP_CHECK(hipMalloc((void **)&h->d_in, in_n * sizeof(double))); h->in_cap = in_n; }
     if (out_n > h->out_cap) { if (h->d_out) hipFree(h->d_out); DSS_HIP_CHECK(hipMalloc((void **)&h->d_out, out_n * sizeof(double))); h->out_cap = out_n; }
     DSS_HIP_CHECK(hipMemcpy(h->d_in, data, in_n * sizeof(double), hipMemcpyHostToDevice));
-    const int W = dss_hga_extract_dev(h, h->d_in, n, h->d_out, 0, nullptr);
+    int W;
+    { HgaNoZs guard(h); W = dss_hga_extract_dev(h, h->d_in, n, h->d_out, 0, nullptr); }
     if (W < 0) return W;
     if (W == 0) { DSS_HIP_CHECK(hipDeviceSynchronize()); return 0; }
     const size_t cnt = (size_t)h->d.S * W * h->d.C;
     DSS_HIP_CHECK(hipMemcpy(out, h->d_out, cnt * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < cnt; ++k) out[k] = log(out[k]);                 // pyx:46, host libm (DESIGN.md "HGA log")
+    hga_host_finish(h, out, cnt);
     return W;
 }
 
@@ -1446,6 +1498,9 @@ extern "C" int dss_hga_extract_raw_dev(dss_hga *h, const double *d_raw, int n, d
     if (!h || !h->c_raw) { dss_set_error("no front end configured (dss_hga_set_frontend)"); return DSS_EINVAL; }
     if (!d_raw || !d_out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
     DSS_HIP_CHECK(hipSetDevice(h->device));
+    // one launch from the raw packet to the frames: the streamed form, on request (it measured slower than two launches)
+    const DssHgaFrontDev fe = {d_raw, h->c_raw, h->n_grids, h->d_src_col, h->d_grid_of, h->d_comp_cols, h->d_comp_off};
+    if (dss_hga_stream_fits(h->d, &fe)) return hga_run(h, nullptr, &fe, n, d_out, apply_log, (hipStream_t)hip_stream);
     const size_t need = (size_t)h->d.S * n * h->d.C;
     if (need > h->pre_cap) {
         if (h->d_pre) hipFree(h->d_pre);
@@ -1473,12 +1528,13 @@ extern "C" int dss_hga_extract_raw(dss_hga *h, const double *raw, int n, double 
     const size_t out_n = (size_t)h->d.S * (Wmax > 0 ? Wmax : 1) * h->d.C;
     if (out_n > h->out_cap) { if (h->d_out) hipFree(h->d_out); DSS_HIP_CHECK(hipMalloc((void **)&h->d_out, out_n * sizeof(double))); h->out_cap = out_n; }
     DSS_HIP_CHECK(hipMemcpy(h->d_raw, raw, in_n * sizeof(double), hipMemcpyHostToDevice));
-    const int W = dss_hga_extract_raw_dev(h, h->d_raw, n, h->d_out, 0, nullptr);
+    int W;
+    { HgaNoZs guard(h); W = dss_hga_extract_raw_dev(h, h->d_raw, n, h->d_out, 0, nullptr); }
     if (W < 0) return W;
     if (W == 0) { DSS_HIP_CHECK(hipDeviceSynchronize()); return 0; }
     const size_t cnt = (size_t)h->d.S * W * h->d.C;
     DSS_HIP_CHECK(hipMemcpy(out, h->d_out, cnt * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < cnt; ++k) out[k] = log(out[k]);                 // pyx:46, host libm (DESIGN.md "HGA log")
+    hga_host_finish(h, out, cnt);
     return W;
 }
 

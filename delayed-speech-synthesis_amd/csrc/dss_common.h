@@ -170,9 +170,20 @@ struct DssHgaDev {
     double *zi;        // [S][2][8][2][C]
     double *rows;      // [S][cap_rows][C]
     double sos[2][8][6];
+    const double *zs_mean, *zs_std;   // optional z-score of the frames, [C] each (device-resident entry points)
+    int force_path;    // tests / A-B timing only: 0 choose, 1 hga_fused_kernel, 2 the three-launch form, 3 hga_stream_kernel
 };
-int dss_launch_hga(const DssHgaDev &h, const double *d_data, int n, int row0, int zero_rows, int rows, int W,
-                   double *d_out, int apply_log, hipStream_t s);
+// the front end of a call (local/common.py:16-58,308-345): raw amplifier rows (S, n, c_raw) instead of (S, n, C)
+struct DssHgaFrontDev {
+    const double *raw;
+    int c_raw, n_grids;
+    const int *src_col, *grid_of, *comp_cols, *comp_off;
+};
+// fe == nullptr: d_data is (S, n, C).  With fe: returns DSS_EINVAL when the one-launch form cannot take this shape
+// (C not a multiple of 16, or the tiles do not fit LDS); the caller then runs dss_launch_hga_frontend first.
+int dss_hga_stream_fits(const DssHgaDev &h, const DssHgaFrontDev *fe);
+int dss_launch_hga(const DssHgaDev &h, const double *d_data, const DssHgaFrontDev *fe, int n, int row0, int zero_rows, int rows,
+                   int W, double *d_out, int apply_log, hipStream_t s);
 int dss_launch_hga_frontend(const double *d_raw, double *d_pre, int S, int n, int c_raw, int C, const int *src_col,
                             const int *grid_of, int n_grids, const int *comp_cols, const int *comp_off, hipStream_t s);
 int dss_launch_hga_reset(const DssHgaDev &h, const double *d_zi_hg, const double *d_zi_fh, hipStream_t s);

@@ -100,6 +100,23 @@ class HgaExtractorGPU:
     def frames_for(self, n: int) -> int:
         return int(self._L.dss_hga_frames_for(self._h, int(n)))
 
+    def set_zscore(self, means=None, stds=None):
+        """ZScoreNormalization (local/common.py:367-376) as the epilogue of the extractor's own launch:
+        frames -> (frames - means) / stds.  ``None`` clears it.  (dss_hga_set_zscore)"""
+        if means is None:
+            _lib.check(self._L.dss_hga_set_zscore(self._h, None, None))
+            return
+        m = np.ascontiguousarray(means, dtype=np.float64)
+        sd = np.ascontiguousarray(stds, dtype=np.float64)
+        if m.shape != (self.C,) or sd.shape != (self.C,):
+            raise ValueError(f"means / stds must have shape ({self.C},)")
+        _lib.check(self._L.dss_hga_set_zscore(self._h, m.ctypes.data, sd.ctypes.data))
+
+    def _force_path(self, path: int):
+        """Tests / A-B timing only: 0 choose, 1 hga_fused_kernel, 2 three launches, 3 hga_stream_kernel (one launch also for raw
+        packets) (dss_selftest_hga_force_path)."""
+        _lib.check(self._L.dss_selftest_hga_force_path(self._h, int(path)))
+
     def extract(self, data: np.ndarray) -> np.ndarray:
         """(S, n, C) float64 host -> (S, W, C) float64 host, bit-identical to the reference chain."""
         d = np.ascontiguousarray(data, dtype=np.float64)

@@ -49,14 +49,22 @@ class SegmentPipeline(_DecoderMixin):
         std = np.ones(n_channels) if channel_stds is None else np.asarray(channel_stds, dtype=np.float64)
         self.mean = torch.from_numpy(mean).cuda()
         self.std = torch.from_numpy(std).cuda()
+        self._zs = (mean, std)
+        self._zs_in_kernel = True                             # ZScoreNormalization as the epilogue of the HGA launch
 
     @torch.no_grad()
     def __call__(self, ecog: torch.Tensor, return_intermediates: bool = False):
         """ecog: CUDA float64 (B, n_samples, C).  Returns int16 CUDA (B, frames*160)."""
         self.hga.reset()                                   # a fresh extractor per segment (prepare_corpus.py:147-176)
         self.vocoder.reset_async()                         # a fresh decoder per segment (training.py:193)
-        hga = self.hga.extract_torch(ecog, apply_log=True)                    # (B, W, C) float64
-        z = ((hga - self.mean) / self.std).to(torch.float32)                  # ZScoreNormalization, then .float()
+        if self._zs_in_kernel and not return_intermediates:
+            self.hga.set_zscore(*self._zs)
+            hga = None
+            z = self.hga.extract_torch(ecog, apply_log=True).to(torch.float32)    # z-scored frames straight from the launch
+        else:                                                                 # (test tap: the frames before the z-score)
+            self.hga.set_zscore(None)
+            hga = self.hga.extract_torch(ecog, apply_log=True)                # (B, W, C) float64
+            z = ((hga - self.mean) / self.std).to(torch.float32)              # ZScoreNormalization, then .float()
         feats, _ = self.decoder(z, self.decoder.create_new_initial_state(batch_size=self.B, device="cuda"))
         pcm = self.vocoder.synthesize_torch(feats.contiguous())
         return (pcm, hga, feats) if return_intermediates else pcm
@@ -155,6 +163,9 @@ class GatedStreamingPipeline(_DecoderMixin):
         mean = np.zeros(n_channels) if channel_means is None else np.asarray(channel_means, dtype=np.float64)
         std = np.ones(n_channels) if channel_stds is None else np.asarray(channel_stds, dtype=np.float64)
         self.mean, self.std = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
+        self._zs_in_kernel = True                             # ZScoreNormalization as the epilogue of the HGA launch
+        if self._zs_in_kernel:
+            self.hga.set_zscore(mean, std)
         self._in = torch.empty((n_streams, packet, n_channels), dtype=torch.float64, device="cuda")
         self.frame_counter = 0
         self.last_labels = None           # raw VAD decisions and z-scored frames of the last tick (test taps)
@@ -169,7 +180,8 @@ class GatedStreamingPipeline(_DecoderMixin):
         W = hga.shape[1]
         if W == 0:
             return []
-        z = ((hga - self.mean) / self.std).contiguous()                               # post-transform (ZScoreNormalization)
+        # post-transform (ZScoreNormalization): already applied inside the launch when the channel count allows
+        z = hga if self._zs_in_kernel else ((hga - self.mean) / self.std).contiguous()
         logits, self.vad_state = self.vad(z.to(torch.float32), self.vad_state)       # units.py:433-434
         labels = torch.argmax(logits, dim=2).to(torch.int32).contiguous()
         self.last_labels, self.last_z = labels, z

@@ -211,6 +211,16 @@ int dss_hga_extract_raw_dev(dss_hga *h, const double *d_raw, int n, double *d_ou
 /* Device-resident form: d_data / d_out device pointers; log applied on the device (OCML log, <= 1 ulp
  * from the host's) when apply_log != 0, else out = mean power + 0.01. */
 int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, int apply_log, void *hip_stream);
+/* Optional last step of the reference's feature chain inside the extractor's launch: ZScoreNormalization,
+ * (frame - means[c]) / stds[c] (local/common.py:367-376; decode_online.py:88-97 puts it behind HighGammaActivity as a
+ * post-transform).  means / stds: host arrays of n_channels doubles, both NULL to clear.  The device-resident entry
+ * points then return z-scored frames; the host-buffer ones apply it on the host after their host-libm log.  (The
+ * three-launch fallback for window shapes whose ring does not fit LDS has no epilogue: such a call fails with DSS_EINVAL.) */
+int dss_hga_set_zscore(dss_hga *h, const double *means, const double *stds);
+/* Tests and A/B timing only: which kernel form serves this extractor.  0 = choose (default: hga_fused_kernel; three
+ * launches when its ring does not fit LDS), 1 = hga_fused_kernel, 2 = the three-launch form, 3 = hga_stream_kernel (one
+ * launch from the raw packet to the z-scored frames; a multiple of 16 channels; exact, measured slower: DESIGN.md 5). */
+int dss_selftest_hga_force_path(dss_hga *h, int path);
 
 /* ------------------------------------------------------------------------------------------------
  * Part 4 -- speech-segment gate for n_streams streams: the two ring buffers the

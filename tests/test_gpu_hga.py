@@ -129,3 +129,85 @@ def test_other_window_shapes_against_the_oracle(oracle, fs, wl, ws, packets):
         pos += n
         total += len(want)
     assert total > 0
+
+
+def test_streamed_kernel_equals_the_other_forms(golden):
+    """The three forms of the extractor -- hga_fused_kernel (default), the three launches, hga_stream_kernel (filter waves +
+    helper waves, opt-in) -- give the same bits: offline trials, 40-sample packets, ragged packets (tiles that end inside
+    a packet, packets shorter than a tile, a first packet shorter than a frame)."""
+    import torch
+    from dss_amd.hga import HgaExtractorGPU
+    S = 11                                                     # not a multiple of 8: exercises the block -> stream mapping's tail
+    xs = np.stack([synthetic_ecog(6000 + s, 1040, 64) for s in range(S)])
+    d = torch.from_numpy(xs).cuda()
+    res = {}
+    for path in (0, 2, 3):
+        ex = HgaExtractorGPU(S, 64, filters=_filters(golden))
+        ex._force_path(path)
+        whole = ex.extract_torch(d, apply_log=False).cpu().numpy()
+        ex.reset()
+        parts, pos = [], 0
+        for n in (13, 40, 40, 17, 100, 64, 23, 200, 543):
+            parts.append(ex.extract_torch(d[:, pos:pos + n].contiguous(), apply_log=False).cpu().numpy())
+            pos += n
+        res[path] = (whole, np.concatenate(parts, axis=1))
+    assert res[0][0].shape == (S, 100, 64)
+    for path in (2, 3):
+        assert np.array_equal(res[0][0], res[path][0]), path
+        assert np.array_equal(res[0][1], res[path][1]), path
+    g = golden("hga_frames.npz")                               # and the reference's own frames, through the streamed kernel
+    ex = HgaExtractorGPU(4, 64, filters=_filters(golden))
+    ex._force_path(3)
+    got = ex.extract(np.stack([synthetic_ecog(1000 + b, 1040, 64) for b in range(4)]))
+    for b in range(4):
+        assert np.array_equal(got[b], g[f"offline{b}_out"])
+
+
+def test_raw_packets_and_zscore_in_one_launch(golden):
+    """raw 129-column packets -> reorder + per-grid CAR + select -> filters -> log power -> z-score, as two
+    launches (front end, then the extractor with the z-score as its epilogue: the default) and as ONE launch
+    (hga_stream_kernel, front end inside the helper waves: opt-in).  Both equal, bit for bit, a host / torch z-score of the
+    plain frames; odd packet lengths make the raw rows start on 8-byte boundaries."""
+    import torch
+    from dss_amd.electrodes import reference_frontend
+    from dss_amd.hga import HgaExtractorGPU
+    S = 9
+    rng = np.random.default_rng(3)
+    raw = rng.standard_normal((S, 677, 129)) * 40.0
+    mean, std = rng.standard_normal(64), rng.uniform(0.5, 2.0, 64)
+    d = torch.from_numpy(raw).cuda()
+    outs = {}
+    for path in (0, 3):
+        ex = HgaExtractorGPU(S, 64, filters=_filters(golden))
+        ex.set_frontend(129, *reference_frontend())
+        ex._force_path(path)
+        parts, pos = [], 0
+        for n in (77, 40, 41, 319, 200):
+            parts.append(ex.extract_raw_torch(d[:, pos:pos + n].contiguous(), apply_log=False).cpu().numpy())
+            pos += n
+        outs[path] = np.concatenate(parts, axis=1)
+    assert outs[0].shape[1] > 50 and np.array_equal(outs[0], outs[3])
+    # z-score epilogue: device-resident (log on the device) and host-buffer (glibc log) entry points, both forms
+    for path in (0, 3):
+        ex = HgaExtractorGPU(S, 64, filters=_filters(golden))
+        ex.set_frontend(129, *reference_frontend())
+        ex._force_path(path)
+        plain = ex.extract_raw_torch(d)                                         # log applied, no z-score
+        ex.reset()
+        ex.set_zscore(mean, std)
+        z = ex.extract_raw_torch(d)
+        assert torch.equal(z, (plain - torch.from_numpy(mean).cuda()) / torch.from_numpy(std).cuda()), path
+        ex.reset()
+        zh = ex.extract_raw(raw)
+        ex.reset()
+        ex.set_zscore(None)
+        ph = ex.extract_raw(raw)
+        assert np.array_equal(zh, (ph - mean) / std), path
+    # odd channel counts take the z-score too (hga_fused_kernel's epilogue)
+    x5 = synthetic_ecog(9, 300, 5)
+    e5 = HgaExtractorGPU(1, 5, filters=_filters(golden))
+    p5 = e5.extract_torch(torch.from_numpy(x5[None]).cuda())
+    e5.reset()
+    e5.set_zscore(mean[:5], std[:5])
+    z5 = e5.extract_torch(torch.from_numpy(x5[None]).cuda())
+    assert torch.equal(z5, (p5 - torch.from_numpy(mean[:5]).cuda()) / torch.from_numpy(std[:5]).cuda())

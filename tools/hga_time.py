@@ -1,4 +1,4 @@
-"""Development aid: HGA extractor timing, fused single launch vs the three-launch form (DSS_HGA_SPLIT=1), and the front end."""
+"""Development aid: HGA extractor timing: hga_fused_kernel (default), the three-launch form (DSS_HGA_PATH=2), the streamed one-launch form (=3)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "delayed-speech-synthesis_amd"))
@@ -14,10 +14,12 @@ def timeit(fn, n=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n
 
-tag = "3 launches" if os.environ.get("DSS_HGA_SPLIT") else "fused"
+PATH = int(os.environ.get("DSS_HGA_PATH", "0"))          # 0 default (fused), 2 three launches, 3 streamed (one launch, opt-in)
+tag = {0: "fused", 1: "fused", 2: "3 launches", 3: "streamed"}[PATH]
 for S in (64, 1024):
     x = torch.from_numpy(np.stack([synthetic_ecog(1000 + b % 8, 1040, 64) for b in range(S)])).cuda()
     ex = HgaExtractorGPU(S, 64)
+    ex._force_path(PATH)
     def run():
         ex.reset(); ex.extract_torch(x, apply_log=True)
     dt = timeit(run)
@@ -26,11 +28,13 @@ for S in (64, 1024):
     print(f"[{tag}] HGA {S} x 1.04 s x 64 ch: {dt*1e3:.3f} ms -> {S*1.04/dt:.0f} stream-s/s, {gb/dt:.0f} GB/s algorithmic, {gf/dt/1e3:.2f} TFLOP/s fp64 (no-FMA peak 39.3)")
 S = 128
 ex = HgaExtractorGPU(S, 64)
+ex._force_path(PATH)
 pk = torch.from_numpy(np.random.default_rng(0).standard_normal((S, 40, 64)) * 50).cuda()
 ex.extract_torch(pk)
 print(f"[{tag}] streaming tick, 128 streams x 40-sample packet: {timeit(lambda: ex.extract_torch(pk), 50)*1e3:.4f} ms")
 raw = torch.from_numpy(np.random.default_rng(1).standard_normal((1024, 1040, 129)) * 50).cuda()
 ex = HgaExtractorGPU(1024, 64)
+ex._force_path(PATH)
 ex.set_frontend(129, *reference_frontend())
 def run2():
     ex.reset(); ex.extract_raw_torch(raw)
