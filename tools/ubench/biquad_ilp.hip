@@ -13,10 +13,12 @@ __device__ __forceinline__ double shift_in(double x, double y)
     const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(ux >> 32), (int)(unsigned)(uy >> 32), 0x111, 0xf, 0xf, false);
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
-template <int NC>
+template <int NC, int STORE>
 __global__ void __launch_bounds__(256) k(const double *coef, double *out, long long *cyc, int steps)
 {
     __shared__ double xs[64][64];
+    __shared__ double ys[64][16];
+    __shared__ double dump[256];
     for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) xs[i >> 6][i & 63] = 1e-3 * (i % 97);
     __syncthreads();
     const int r = threadIdx.x & 15, pib = threadIdx.x >> 4;
@@ -31,6 +33,8 @@ __global__ void __launch_bounds__(256) k(const double *coef, double *out, long l
             for (int c = 0; c < NC; ++c) {
                 const double in = shift_in(xs[(k4 + u) & 63][pib + 16 * c], y[c]);
                 y[c] = b0 * in + z0[c];
+                if (STORE == 1) { if (r == 15) ys[(k4 + u) & 63][pib] = y[c]; }                       // exec-masked store, last section's lane
+                if (STORE == 2) { *(r == 15 ? &ys[(k4 + u) & 63][pib] : &dump[threadIdx.x]) = y[c]; }  // every lane stores
                 z0[c] = b1 * in - a1 * y[c] + z1[c];
                 z1[c] = b2 * in - a2 * y[c];
             }
@@ -55,18 +59,18 @@ __global__ void addchain(double *out, long long *cyc, double seed)
     out[threadIdx.x] = a;
     if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
-template <int NC> int run(const double *dc, double *dout, long long *dcyc, int blocks_per_cu)
+template <int NC, int STORE = 0> int run(const double *dc, double *dout, long long *dcyc, int blocks_per_cu)
 {
     const int steps = 2048, blocks = 256 * blocks_per_cu;
-    hipLaunchKernelGGL(k<NC>, dim3(blocks), dim3(256), 0, 0, dc, dout, dcyc, steps);
-    hipLaunchKernelGGL(k<NC>, dim3(blocks), dim3(256), 0, 0, dc, dout, dcyc, steps);
+    hipLaunchKernelGGL((k<NC, STORE>), dim3(blocks), dim3(256), 0, 0, dc, dout, dcyc, steps);
+    hipLaunchKernelGGL((k<NC, STORE>), dim3(blocks), dim3(256), 0, 0, dc, dout, dcyc, steps);
     CHECK(hipDeviceSynchronize());
     std::vector<long long> c(blocks * 4);
     CHECK(hipMemcpy(c.data(), dcyc, c.size() * 8, hipMemcpyDeviceToHost));
     double s = 0; for (auto v : c) s += (double)v;
     const double per_step = s / c.size() / steps;
-    printf("%d column(s) per lane, %d block(s) of 4 waves per CU: %7.1f cycles per step and wave = %6.1f per column-step; per SIMD %6.1f cycles per column-step\n",
-           NC, blocks_per_cu, per_step, per_step / NC, per_step / NC / blocks_per_cu);
+    printf("store mode %d: %d column(s) per lane, %d block(s) of 4 waves per CU: %7.1f cycles per step and wave = %6.1f per column-step; per SIMD %6.1f cycles per column-step\n",
+           STORE, NC, blocks_per_cu, per_step, per_step / NC, per_step / NC / blocks_per_cu);
     return 0;
 }
 int main()
@@ -80,5 +84,6 @@ int main()
     long long c0; CHECK(hipMemcpy(&c0, dcyc, 8, hipMemcpyDeviceToHost));
     printf("dependent v_add_f64: %.1f cycles each (one wave)\n", (double)c0 / 4096.0);
     for (int bpc : {1, 2, 3, 5}) { run<1>(dc, dout, dcyc, bpc); run<2>(dc, dout, dcyc, bpc); run<4>(dc, dout, dcyc, bpc); }
+    for (int bpc : {1, 3, 5, 8}) { run<1, 0>(dc, dout, dcyc, bpc); run<1, 1>(dc, dout, dcyc, bpc); run<1, 2>(dc, dout, dcyc, bpc); }
     return 0;
 }
