@@ -168,21 +168,26 @@ hga_filter_kernel(const double *__restrict__ data, double *__restrict__ zi, doub
 
 // ---- fused form: filter tile -> LDS ring -> completed windows -> overlap rows -------------------------------------------
 // Same block shape and the same per-step code as hga_filter_kernel (16 columns x 16 section lanes).  `ring` holds the last
-// RING rows of the block's 16 columns in row coordinates (overlap / zero rows first, then the new samples at row0 + t);
-// RING >= frame_length + window shift + HGA_TT so that no row a pending window still needs is overwritten by the next tile.
-__global__ void __launch_bounds__(256)
+// R rows of the block's 16 columns (overlap / zero rows first, then the new samples at row0 + t), row i at position i mod R;
+// R >= frame_length + window shift + TT + 2 so that no row a pending window still needs is overwritten by the next tile.
+// Round 3: R carries no power-of-two padding and the lanes that do not hold the last section have no dummy store targets
+// any more (18 KB of static LDS + 16 KB of ring instead of 37 KB).  A 32-step-tile instantiation (22 KB, 7 blocks per CU
+// instead of 5) is kept for A/B timing: it is no faster at 1024 streams and slower on small calls (profiles/
+// r3_hga_tile_ab_timing.txt), so 64-step tiles stay the default.
+#define HGF_WTAB 128
+template <int TT>
+__global__ void __launch_bounds__(256, TT == 32 ? 7 : 4)
 hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, double *__restrict__ rowbuf, double *__restrict__ out,
                  HgaSos sos, int S, int C, int n, int nsec, int row0, int cap_rows, int zero_rows, int rows, int W, int overlap,
-                 int sr, float wl, float ws, int apply_log, int ring_mask, const double *__restrict__ zs_mean,
+                 int sr, float wl, float ws, int apply_log, int R, const double *__restrict__ zs_mean,
                  const double *__restrict__ zs_std)
 {
-    __shared__ double xs[HGA_TT + 1][16];
-    __shared__ double ys[HGA_TT][16];
+    __shared__ double xs[TT + 1][16];
+    __shared__ double ys[TT][16];
     __shared__ double coef[16][5];
-    __shared__ double dump[256];
-    __shared__ int wtab[2][HGA_WTAB];          // first and one-past-last row of the first HGA_WTAB windows (the float32 /
+    __shared__ int wtab[2][HGF_WTAB];          // first and one-past-last row of the first HGF_WTAB windows (the float32 /
                                                //   round() arithmetic of pyx:43-44 once per block instead of once per tile)
-    extern __shared__ __attribute__((aligned(16))) double ring[];         // [ring_mask + 1][16]
+    extern __shared__ __attribute__((aligned(16))) double ring[];         // [R][16]
     const int tid = threadIdx.x, r = tid & 15, pib = tid >> 4;
     const long total = (long)S * C;
     const long pair0 = (long)blockIdx.x * 16;
@@ -193,8 +198,6 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
     const int nsec2 = 2 * nsec;
     const bool has_sec = r < nsec2;
     const bool is_last = r == nsec2 - 1;
-    char *const ybase = is_last ? reinterpret_cast<char *>(&ys[0][pib]) : reinterpret_cast<char *>(&dump[tid]);
-    const int ystride = is_last ? 16 * (int)sizeof(double) : 0;
     const int f = has_sec ? r / nsec : 0, q = has_sec ? r - f * nsec : 0;
     if (tid < 16) {
         const int ff = tid < nsec2 ? tid / nsec : 0, qq = tid < nsec2 ? tid - ff * nsec : 0;
@@ -203,7 +206,7 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
     }
     double *zp = zi + (size_t)s * 2 * 8 * 2 * C + c;
     double z0 = zp[((f * 8 + q) * 2 + 0) * (size_t)C], z1 = zp[((f * 8 + q) * 2 + 1) * (size_t)C];
-    for (int w = tid; w < W && w < HGA_WTAB; w += 256) {
+    for (int w = tid; w < W && w < HGF_WTAB; w += 256) {
         const int st = hga_win_start(w, ws, sr);
         wtab[0][w] = st;
         wtab[1][w] = hga_win_stop(st, wl, sr);
@@ -217,7 +220,7 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
             const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
             v = rowbuf[((size_t)sp * cap_rows + rr) * C + cp];
         }
-        ring[(rr & ring_mask) * 16 + p] = v;
+        ring[(rr % R) * 16 + p] = v;
     }
     __syncthreads();
     const double b0 = coef[r][0], b1 = coef[r][1], b2 = coef[r][2], a1 = coef[r][3], a2 = coef[r][4];
@@ -232,20 +235,22 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
     const bool lvalid = lpp < total;
     const double *lcol = data;
     if (lvalid) { const int sp = (int)(lpp / C), cp = (int)(lpp - (long)sp * C); lcol = data + (size_t)sp * n * C + cp; }
-    double pre[HGA_TT / 16];
-#define HGA_FETCH(BASE)                                                                          \
-    _Pragma("unroll") for (int j = 0; j < HGA_TT / 16; ++j) {                                    \
+    double pre[TT / 16];
+#define HGF_FETCH(BASE)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < TT / 16; ++j) {                                        \
         const int t = (BASE) + ltt + 16 * j;                                                     \
         pre[j] = (lvalid && t < n) ? lcol[(size_t)t * C] : 0.0;                                  \
     }
-    HGA_FETCH(0)
-    for (int base = 0; base < steps; base += HGA_TT) {
+    HGF_FETCH(0)
+    // ring position of row (row0 + t) for the first output of the current tile, kept modulo R (block-uniform)
+    int tile_pos = (row0 + R * 16 - (nsec2 - 1)) % R;      // row0 + t for t = 0 - (nsec2 - 1): the row "before" the first output
+    for (int base = 0; base < steps; base += TT) {
         __syncthreads();                                   // previous tile fully consumed
 #pragma unroll
-        for (int j = 0; j < HGA_TT / 16; ++j) xs[ltt + 16 * j][lp] = pre[j];
-        if (base + HGA_TT < steps) { HGA_FETCH(base + HGA_TT) }
+        for (int j = 0; j < TT / 16; ++j) xs[ltt + 16 * j][lp] = pre[j];
+        if (base + TT < steps) { HGF_FETCH(base + TT) }
         __syncthreads();
-        const int kend = min(base + HGA_TT, steps);
+        const int kend = min(base + TT, steps);
         int k = base;
         for (; k < kend && (k < nsec2 - 1 || k >= n); ++k) {
             const double in = hga_shift_in(xs[k - base][pib], y);
@@ -257,7 +262,6 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
         }
         const int ksteady = min(kend, n);
         {
-            char *yp = ybase + (k - base) * ystride;
             const double *xp = &xs[k - base][pib];
             double xcur = *xp;
             // four steps per trip with constant LDS offsets (a DPP move is convergent: the compiler will not unroll a loop of
@@ -274,15 +278,11 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
                     xcur = xnext;
                 }
             }
-            xp += 16 * kk;
-            yp += kk * ystride;
-            for (; k < ksteady; ++k) {
-                xp += 16;
-                const double xnext = *xp;
+            for (; k < ksteady; ++k, ++kk) {
+                const double xnext = xp[16 * (kk + 1)];
                 const double in = hga_shift_in(xcur, y);
                 HGA_BIQUAD(in)
-                *reinterpret_cast<double *>(yp) = y;
-                yp += ystride;
+                if (is_last) yl[16 * kk] = y;
                 xcur = xnext;
             }
         }
@@ -295,12 +295,16 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
             }
         }
         __syncthreads();
-        // the tile's finished samples join the ring at their row
-        for (int idx = tid; idx < HGA_TT * 16; idx += 256) {
+        // the tile's finished samples join the ring at their row (position row mod R, advanced from tile to tile)
+        for (int idx = tid; idx < TT * 16; idx += 256) {
             const int tt = idx >> 4, p = idx & 15;
             const int t = base + tt - (nsec2 - 1);
-            if (base + tt < kend && t >= 0 && t < n) ring[((row0 + t) & ring_mask) * 16 + p] = ys[tt][p];
+            int pos = tile_pos + tt;
+            if (pos >= R) pos -= R;
+            if (base + tt < kend && t >= 0 && t < n) ring[pos * 16 + p] = ys[tt][p];
         }
+        tile_pos += TT;
+        if (tile_pos >= R) tile_pos -= R;
         __syncthreads();
         // every window that is complete now: lane = (window, column), a sequential sum over its rows (pyx:9-22, 42-46)
         int t_done = kend - (nsec2 - 1);
@@ -310,21 +314,29 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
             const int p = tid & 15, wi = tid >> 4;
             const long pp = pair0 + p;
             for (int w = w_next + wi; w < W; w += 16) {
-                const int start = w < HGA_WTAB ? wtab[0][w] : hga_win_start(w, ws, sr);
-                const int stop = w < HGA_WTAB ? wtab[1][w] : hga_win_stop(start, wl, sr);
+                const int start = w < HGF_WTAB ? wtab[0][w] : hga_win_start(w, ws, sr);
+                const int stop = w < HGF_WTAB ? wtab[1][w] : hga_win_stop(start, wl, sr);
                 if (stop > rows_done) break;
                 double sum = 0.0;
-                int rr = start;
-                for (; rr + 8 <= stop; rr += 8) {          // eight ring reads in flight, then their terms in row order
-                    double v[8];
+                // the window's rows sit at positions start mod R ... (wrapping once at most: stop - start <= R)
+                int pos = start % R, left = stop - start;
+                while (left > 0) {
+                    const int run = min(left, R - pos);
+                    const double *rp = ring + pos * 16 + p;
+                    int i = 0;
+                    for (; i + 8 <= run; i += 8) {             // eight ring reads in flight, then their terms in row order
+                        double v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = ring[((rr + u) & ring_mask) * 16 + p];
+                        for (int u = 0; u < 8; ++u) v[u] = rp[(i + u) * 16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) sum += v[u] * v[u];
-                }
-                for (; rr < stop; ++rr) {
-                    const double v = ring[(rr & ring_mask) * 16 + p];
-                    sum += v * v;
+                        for (int u = 0; u < 8; ++u) sum += v[u] * v[u];
+                    }
+                    for (; i < run; ++i) {
+                        const double v = rp[i * 16];
+                        sum += v * v;
+                    }
+                    left -= run;
+                    pos = 0;
                 }
                 if (pp < total) {
                     const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
@@ -334,7 +346,7 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
                     out[((size_t)sp * W + w) * C + cp] = o;
                 }
             }
-            while (w_next < W && (w_next < HGA_WTAB ? wtab[1][w_next] : hga_win_stop(hga_win_start(w_next, ws, sr), wl, sr)) <= rows_done)
+            while (w_next < W && (w_next < HGF_WTAB ? wtab[1][w_next] : hga_win_stop(hga_win_start(w_next, ws, sr), wl, sr)) <= rows_done)
                 ++w_next;
         }
     }
@@ -345,13 +357,14 @@ hga_fused_kernel(const double *__restrict__ data, double *__restrict__ zi, doubl
         const long pp = pair0 + p;
         if (pp < total) {
             const int sp = (int)(pp / C), cp = (int)(pp - (long)sp * C);
-            rowbuf[((size_t)sp * cap_rows + kk) * C + cp] = ring[((rows - overlap + kk) & ring_mask) * 16 + p];
+            rowbuf[((size_t)sp * cap_rows + kk) * C + cp] = ring[((rows - overlap + kk) % R) * 16 + p];
         }
     }
     if (valid && has_sec) {
         zp[((f * 8 + q) * 2 + 0) * (size_t)C] = z0;
         zp[((f * 8 + q) * 2 + 1) * (size_t)C] = z1;
     }
+#undef HGF_FETCH
 }
 
 // ---- streamed form (opt-in): four filter waves that only filter, two helper waves that feed and drain them
@@ -795,14 +808,20 @@ int dss_launch_hga(const DssHgaDev &h, const double *d_data, const DssHgaFrontDe
         }
     }
     if (fe) { dss_set_error("HGA: the one-launch front end needs the streamed form, a multiple of 16 channels and tiles that fit LDS"); return DSS_EINVAL; }
-    if (h.force_path != 2) {   // fused form when the ring (frame + shift + one tile of rows, rounded up to a power of two) fits beside the tiles
-        int ring_rows = 64;
-        while (ring_rows < h.frame_length + shift + HGA_TT + 2) ring_rows *= 2;
+    if (h.force_path != 2) {   // fused form when the ring (frame + shift + one tile of rows) fits beside the tiles
+        const int TT = h.force_path == 1 ? 32 : 64;                  // 1: 32-step tiles, 7 blocks per CU instead of 5 (A/B timing: no faster)
+        int ring_rows = h.frame_length + shift + TT + 2;
+        ring_rows = (ring_rows + 7) & ~7;
         const size_t ring_bytes = (size_t)ring_rows * 16 * sizeof(double);
-        if (ring_bytes <= 40 * 1024 && rows - h.overlap + HGA_TT <= (1 << 30) && h.overlap <= ring_rows) {
-            hipLaunchKernelGGL(hga_fused_kernel, dim3((unsigned)((pairs + 15) / 16)), dim3(256), ring_bytes, st, d_data, h.zi, h.rows,
-                               d_out, sos, h.S, h.C, n, h.nsec, row0, h.cap_rows, zero_rows, rows, W, h.overlap, h.fs, h.wl, h.ws,
-                               apply_log, ring_rows - 1, h.zs_mean, h.zs_std);
+        if (ring_bytes <= 40 * 1024 && rows - h.overlap + TT <= (1 << 30) && h.overlap <= ring_rows && row0 <= ring_rows) {
+            if (TT == 32)
+                hipLaunchKernelGGL(hga_fused_kernel<32>, dim3((unsigned)((pairs + 15) / 16)), dim3(256), ring_bytes, st, d_data, h.zi,
+                                   h.rows, d_out, sos, h.S, h.C, n, h.nsec, row0, h.cap_rows, zero_rows, rows, W, h.overlap, h.fs, h.wl,
+                                   h.ws, apply_log, ring_rows, h.zs_mean, h.zs_std);
+            else
+                hipLaunchKernelGGL(hga_fused_kernel<64>, dim3((unsigned)((pairs + 15) / 16)), dim3(256), ring_bytes, st, d_data, h.zi,
+                                   h.rows, d_out, sos, h.S, h.C, n, h.nsec, row0, h.cap_rows, zero_rows, rows, W, h.overlap, h.fs, h.wl,
+                                   h.ws, apply_log, ring_rows, h.zs_mean, h.zs_std);
             DSS_HIP_CHECK(hipGetLastError());
             return DSS_OK;
         }

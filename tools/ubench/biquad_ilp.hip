@@ -16,10 +16,10 @@ __device__ __forceinline__ double shift_in(double x, double y)
 template <int NC, int STORE>
 __global__ void __launch_bounds__(256) k(const double *coef, double *out, long long *cyc, int steps)
 {
-    __shared__ double xs[64][64];
+    __shared__ double xs[64][16 * NC];       // (with the stores: 8 + 8 + 2 KB per block at one column per lane, so that 8 blocks per CU are resident)
     __shared__ double ys[64][16];
     __shared__ double dump[256];
-    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) xs[i >> 6][i & 63] = 1e-3 * (i % 97);
+    for (int i = threadIdx.x; i < 64 * 16 * NC; i += blockDim.x) xs[i / (16 * NC)][i % (16 * NC)] = 1e-3 * (i % 97);
     __syncthreads();
     const int r = threadIdx.x & 15, pib = threadIdx.x >> 4;
     const double b0 = coef[r], b1 = coef[16 + r], b2 = coef[32 + r], a1 = coef[48 + r], a2 = coef[64 + r];
