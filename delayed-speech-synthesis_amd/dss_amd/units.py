@@ -68,6 +68,17 @@ class HighGammaExtractor:
         if p is not None and len(p) == 3 and hasattr(p[0], "grid_mapping") and hasattr(p[1], "selection_masks_computation") \
                 and hasattr(p[2], "speech_grid_mapping") and len(p[2].speech_grid_mapping) == nb_electrodes:
             self._fused_pre = tuple(p)
+        # decode_online.py:88-97's single post-transform, ZScoreNormalization (common.py:367-376), is recognised the same way
+        # and applied by the library right behind the log (dss_hga_set_zscore): (frames - means) / stds, the same two IEEE
+        # operations numpy performs; any other chain runs on the host as given
+        self._fused_post = False
+        q = post_transforms
+        if q is not None and len(q) == 1 and hasattr(q[0], "channel_means") and hasattr(q[0], "channel_stds"):
+            m = np.asarray(q[0].channel_means, dtype=np.float64).reshape(-1)
+            sd = np.asarray(q[0].channel_stds, dtype=np.float64).reshape(-1)
+            if m.shape == (nb_electrodes,) and sd.shape == (nb_electrodes,):
+                self._gpu.set_zscore(m, sd)
+                self._fused_post = True
 
     def extract_features(self, data: np.ndarray):
         data = np.ascontiguousarray(data, dtype=np.float64)
@@ -79,7 +90,9 @@ class HighGammaExtractor:
             if self.pre_transform is not None:
                 data = np.ascontiguousarray(self.pre_transform(data), dtype=np.float64)
             out = self._gpu.extract(data)[0]
-        return self.post_transform(out) if self.post_transform is not None else out
+        if self._fused_post or self.post_transform is None:
+            return out
+        return self.post_transform(out)
 
 
 class HighGammaActivitySettings(ez.Settings):

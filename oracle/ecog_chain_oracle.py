@@ -56,11 +56,11 @@ class GridCommonAverage:                                # common.py:308-345
 
 
 class ZScore:                                           # common.py:367-376
-    def __init__(self, means, stds):
-        self.means, self.stds = means, stds
+    def __init__(self, channel_means, channel_stds):          # attribute names as in the reference (common.py:371-372)
+        self.channel_means, self.channel_stds = channel_means, channel_stds
 
     def __call__(self, data):
-        return (data - self.means) / self.stds
+        return (data - self.channel_means) / self.channel_stds
 
 
 def reference_chain(bad_channels=(19, 38, 48, 52)):

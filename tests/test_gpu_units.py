@@ -42,6 +42,7 @@ def test_extractor_with_pre_and_post_transforms(golden):
     ex = U.HighGammaExtractor(1000, 64, pre_transforms=[both, car, speech], post_transforms=[post])
     raw = synthetic_ecog(77, 200, 129)
     assert ex._fused_pre is not None                       # reorder + CAR + select run in the GPU front-end kernel
+    assert ex._fused_post                                  # ... and the z-score inside the library, behind the log
     got = ex.extract_features(raw)
     plain = U.HighGammaExtractor(1000, 64).extract_features(speech(car(both(raw))))       # numpy transforms
     assert got.shape == (16, 64) and np.array_equal(got, (plain - 3.0) / 2.0)            # bit-identical
@@ -49,8 +50,9 @@ def test_extractor_with_pre_and_post_transforms(golden):
     more = ex.extract_features(synthetic_ecog(78, 40, 129))
     assert more.shape == (4, 64) and np.isfinite(more).all()
     # a transform chain that is not the reference's falls back to the host transforms
-    ex2 = U.HighGammaExtractor(1000, 64, pre_transforms=[both, speech])
-    assert ex2._fused_pre is None and ex2.extract_features(raw).shape == (16, 64)
+    ex2 = U.HighGammaExtractor(1000, 64, pre_transforms=[both, speech], post_transforms=[post, post])
+    assert ex2._fused_pre is None and not ex2._fused_post
+    assert np.array_equal(ex2.extract_features(raw), post(post(U.HighGammaExtractor(1000, 64).extract_features(speech(both(raw))))))
 
 
 def test_vocoder_unit_segments_and_state_carry(oracle):
