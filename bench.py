@@ -156,7 +156,7 @@ def main():
     cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
 
     def kernel_for(n_utts):     # the library's own rule (csrc/lpcnet_sample.hip dss_launch_sample_network)
-        pair = info["fast_path"] == 1 and info["h_lds_bytes"] <= 131840 and n_utts > max(128, cus)
+        pair = info["fast_path"] == 1 and info["h_lds_bytes"] <= 144896 and n_utts > max(128, cus)
         return "lpcnet_sample_pair_kernel (two utterances per workgroup)" if pair else info["kernel"]
     from dss_amd.distributed import gather_pcm     # the collective the world-size-2 gloo test covers (tests/test_cpu_distributed.py)
     gathered_rows = [0]

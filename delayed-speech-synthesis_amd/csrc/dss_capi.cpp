@@ -559,6 +559,22 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         for (int j = 0; j < NA; ++j)
             for (int row = 0; row < NB3; ++row) gbl[(size_t)j * 64 + row] = v.gru_b_w_in[(size_t)j * NB3 + row];
         rc = dev_upload<float>(gbl.data(), gbl.size(), &df); if (rc) return rc; m.gb_w_lane = df;
+        // ... and four inputs of a lane side by side, for the pair kernel's relay waves, which stream them from L2
+        std::vector<float> gbq((size_t)NA * 64, 0.f);
+        for (int j = 0; j < NA; ++j)
+            for (int row = 0; row < NB3; ++row) gbq[((size_t)(j / 4) * 64 + row) * 4 + (j & 3)] = v.gru_b_w_in[(size_t)j * NB3 + row];
+        rc = dev_upload<float>(gbq.data(), gbq.size(), &df); if (rc) return rc; m.gb_w_quad = df;
+        // dual-FC weights for the pair kernel, whose dual-FC waves load their node's 32 weights every sample instead of
+        // holding them in registers: [k 8][node 256][4] = (layer 0, layer 1) weights of inputs 2k and 2k+1, so that load k
+        // of a wave reads 1 KB of consecutive bytes
+        std::vector<float> fcp((size_t)DSS_FC_OUT * DSS_GRU_B * 2, 0.f);
+        for (int node = 0; node < DSS_FC_OUT; ++node)
+            for (int j = 0; j < DSS_GRU_B; ++j) {
+                const size_t o = ((size_t)(j / 2) * DSS_FC_OUT + node) * 4 + (j & 1) * 2;
+                fcp[o + 0] = v.fc_w[(size_t)node * 2 * DSS_GRU_B + j];
+                fcp[o + 1] = v.fc_w[(size_t)node * 2 * DSS_GRU_B + DSS_GRU_B + j];
+            }
+        rc = dev_upload<float>(fcp.data(), fcp.size(), &df); if (rc) return rc; m.fc_w_pair = df;
     }
     // ---- derived tables (host libm, exactly as xiph builds them at run time) ---------------------------
     {

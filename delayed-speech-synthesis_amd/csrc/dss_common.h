@@ -94,6 +94,8 @@ struct DssModelDev {
     const unsigned *h_col;        // [DSS_HCX/4][384]    same for the h-gate slots of the lane's row group
     const float *hblk;            // LDS image: one list of [8 rows][4] records per row group, lists back to back (see dss_capi.cpp)
     const float *gb_w_lane;       // [384][64] GRU B input weights, input-major, lane = row (rows 48..63 zero)
+    const float *fc_w_pair;       // dual-FC weights as [k 8][node 256][4]: (layer 0, layer 1) weights of inputs 2k, 2k+1 (pair kernel)
+    const float *gb_w_quad;       // the same weights as [384/4][64 lanes][4 inputs]: one 16-byte load per lane and block of four inputs
 };
 
 // ---- per-batch device state ---------------------------------------------------------------------------

@@ -70,16 +70,28 @@ __device__ __forceinline__ float dss_log2_approx(float x)
     return 1 + integer + frac;
 }
 
+// xiph common.h lin2ulaw(), in a shorter instruction sequence that returns the same value for every fp32 input
+// (tools/verify/lin2ulaw_exhaustive.c visits all 2^32 bit patterns against the test suite's restatement of the C source):
+//   * u / 5.5451774445f as q0 = u * (1/c), r = fma(-q0, c, u), q = fma(r, 1/c, q0) -- the correctly rounded quotient for
+//     every numerator that can occur (checked for all 2^-100 < |u| < 2^100), 3 instructions instead of the 11 of an IEEE
+//     division.  The fused operations are internal to the division; they replace v_div_scale/v_rcp/v_fma.../v_div_fixup,
+//     which are fused as well.
+//   * the clamp to [0, 255] as max/min, floor(.5 + (double)u) as floorf(u + .5f): exact for 0 <= u <= 255.
+// The speculation evaluates this 8 times per lane and sample (16 in the two-utterance kernel), between barriers B and
+// C where the CU is issue-bound: 37 -> 21 VALU instructions each.
 __device__ __forceinline__ int dss_lin2ulaw(float x)
 {
     const float scale = 255.f / 32768.f;
-    const int s = (x < 0) ? -1 : 1;
+    const float c = 5.5451774445f, rc = 1.0f / 5.5451774445f;
+    const float s128 = (x < 0) ? -128.f : 128.f;         // s * (128 * t) == (s * 128) * t: both factors are exact scalings
     x = fabsf(x);
-    float u = (s * (128 * (0.69315f * dss_log2_approx(1 + scale * x)) / 5.5451774445f));
+    float u = s128 * (0.69315f * dss_log2_approx(1 + scale * x));
+    const float q0 = u * rc;
+    const float r = __builtin_fmaf(-q0, c, u);
+    u = __builtin_fmaf(r, rc, q0);
     u = 128 + u;
-    if (u < 0) u = 0;
-    if (u > 255) u = 255;
-    return (int)floor(.5 + (double)u);
+    u = __builtin_fminf(__builtin_fmaxf(u, 0.f), 255.f);
+    return (int)floorf(u + .5f);
 }
 
 // kiss99.c

@@ -12,11 +12,12 @@
 // utterances come out bit-identical to the scalar C path -- and to the latency kernel, whose decoder state they share.
 //
 // Why it pays: the CU-resident weights (VGPRs, LDS) are read once for two utterances, and a lone wave issues a packed
-// instruction as fast as a plain one (tools/ubench/simd_share.hip: 4.9 cycles per instruction with two chains), so the
-// serial path of a sample step does twice the work in about 1.2x the time.  The state vectors live in LDS as (A, B)
-// pairs, so one ds_read_b128 feeds two inputs of both utterances.  Packed results are never formed ahead into
-// registers (the latency kernel's 64..96 product registers): the chains multiply as they go, the multiplications of
-// the next block sit in the dependent-latency shadow of the current block's sums.
+// instruction as fast as a plain one (tools/ubench/simd_share.hip: 4.9 cycles per instruction with two chains).  The
+// state vectors live in LDS as (A, B) pairs, so one ds_read_b128 feeds two inputs of both utterances.  The GRU A chains
+// multiply as they go (two utterances' products do not fit beside the weights); GRU B's one long chain is split into
+// seven stages that ping-pong between the two relay waves, each wave forming its next stage's products while the other
+// runs its sums, with the weights streamed from L2 (see DSS_PR_MUL).  The dual-FC waves stream their node's 32 weights
+// the same way, once per sample: between barriers D and C they have no register to spare.
 //
 // The compiler does not fold a broadcast into op_sel (it copies the weight into a register pair instead, which would
 // double the weight registers), so the products are inline asm; the sum chains whose order of issue matters (one
@@ -26,16 +27,19 @@
 #include "lpcnet_sample_common.h"
 #undef HC
 
-#define PGB6 192                          // GRU B inputs whose weights sit in wave 6's VGPRs (0..191)
-#define PGB7 128                          // ... in wave 7's VGPRs (192..319)
-#define PGBL (NA - PGB6 - PGB7)           // ... and the last 64 inputs' weights in LDS, [row][PGL_STRIDE]
-#define PGL_STRIDE 68
-#define DSS_PAIR_HBLK_BYTES 131840        // dynamic LDS left beside PairLds (160 KB per CU)
+#define DSS_PAIR_HBLK_BYTES 144896        // dynamic LDS left beside PairLds (160 KB per CU)
+// Ping-pong relay: the 96 blocks of four inputs go through stages 0..6, even stages on wave 7 (PR7 blocks each), odd
+// ones on wave 6 (PR6 blocks each).  A wave forms the products of its next stage while the other wave runs its sums.
+#ifndef PR7
+#define PR7 12
+#endif
+#define PR6 ((NA / 4 - 4 * PR7) / 3)
+static_assert(4 * PR7 + 3 * PR6 == NA / 4, "stages cover the 96 blocks");
+#define DSS_PR_G0(S) ((((S) + 1) / 2) * PR7 + ((S) / 2) * PR6)      // first block of stage S
 
 struct PairLds {
     float state_a[2][2 * (NA + 4)];       // double-buffered GRU A state, [unit][utterance]; "column 96" = eight zeros
     float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
-    float gb_wl[NB3 * PGL_STRIDE];        // GRU B input weights of the last PGBL inputs, row-major
     float tansig[208];
     float ulaw2lin[256];
     float spec_tab_pred[2][256];          // speculation over all 256 excitation values, per utterance:
@@ -247,7 +251,9 @@ __device__ __forceinline__ void dss_pair_speculate(PairLds &L, int cand, float u
         pc -= q.lo;
         pc -= q.hi;
     }
+    // two evaluations at a time: all four interleaved cost the dual-FC waves registers they do not have
     const int su0 = dss_lin2ulaw(pcm_c.x), su1 = dss_lin2ulaw(pcm_c.y);
+    __builtin_amdgcn_sched_barrier(0);
     const int pu0 = dss_lin2ulaw(pc.x), pu1 = dss_lin2ulaw(pc.y);
     L.spec_tab_pred[0][cand] = pc.x;
     L.spec_tab_pred[1][cand] = pc.y;
@@ -324,35 +330,46 @@ __device__ __forceinline__ void dss_pair_job_init(PairLds &L, const DssBatchDev 
         *reinterpret_cast<f32x2 *>(&L.ah[uh][0]) = ah;                                           \
     }
 
-// GRU B: the chain of one row for both utterances over NBLK blocks of four inputs.  Blocks below G0 take their weights
-// from this lane's registers (WB[k] = inputs 2k, 2k+1), blocks from G0 on from LDS (row-major records, fetched with the
-// state pairs); the new GRU A state pairs come from LDS (same address in every lane: broadcast).  Everything is fetched
-// two blocks ahead of the block being summed; DSS_PGB_HEAD issues the first two fetches (wave 7: under its wait).
-#define DSS_PGB_LOAD(G, G0)                                                                      \
+// ---- GRU B: a ping-pong relay -------------------------------------------------------------------------------------------
+// One dependent chain of 384 sums per row and utterance.  The 96 blocks of four inputs go through seven stages that
+// alternate between waves 7 and 6: while one wave runs the sums of its stage (v_pk_add_f32, (A, B) halves), the other
+// forms the products of its next stage, so the chain itself is sums and hand-overs only.  The weights are not resident:
+// every stage's 4 x PR floats per lane come from L2 (m.gb_w_quad) into the registers the previous stage's weights just left.
+// Products of a stage's NBK blocks, first block G0, into PS[g][0..3]; the state pairs are read two blocks ahead.  The
+// weights of block g sit in RW[g] (four inputs of this lane's row, loaded from m.gb_w_quad); once a block is multiplied
+// its weight registers are reloaded with block g of the wave's NEXT stage (first block GN), which is multiplied a sum
+// stage and a hand-over later: the L2 latency never shows.
+#define DSS_PR_MUL(NBK, G0, GN)                                                                  \
     {                                                                                            \
-        dss_pair_loadx(GX[(G) % 3], an + 32 * (G));                                              \
-        if ((G) >= (G0)) TW[(G) % 3] = *reinterpret_cast<const f32x4 *>(wl + 16 * ((G) - (G0))); \
-    }
-#define DSS_PGB_WLO(G, G0) ((G) < (G0) ? WB[(G) < (G0) ? 2 * (G) : 0] : TW[(G) % 3].lo)
-#define DSS_PGB_WHI(G, G0) ((G) < (G0) ? WB[(G) < (G0) ? 2 * (G) + 1 : 0] : TW[(G) % 3].hi)
-#define DSS_PGB_HEAD(G0)                                                                         \
-    PairX GX[3];                                                                                 \
-    f32x4 TW[3];                                                                                 \
-    f32x2 GP[2][4];                                                                              \
-    DSS_PGB_LOAD(0, G0)                                                                          \
-    DSS_PGB_LOAD(1, G0)
-#define DSS_PGB_RUN(NBLK, G0)                                                                    \
-    {                                                                                            \
-        DSS_PK_MUL4(GP[0], GX[0], DSS_PGB_WLO(0, G0), DSS_PGB_WHI(0, G0));                       \
-        _Pragma("unroll") for (int g = 0; g < (NBLK); ++g) {                                     \
-            if (g + 2 < (NBLK)) DSS_PGB_LOAD(g + 2, G0)                                          \
+        PairX RX[3];                                                                             \
+        dss_pair_loadx(RX[0], an + 32 * (G0));                                                   \
+        dss_pair_loadx(RX[1], an + 32 * ((G0) + 1));                                             \
+        _Pragma("unroll") for (int g = 0; g < (NBK); ++g) {                                      \
+            if (g + 2 < (NBK)) dss_pair_loadx(RX[(g + 2) % 3], an + 32 * ((G0) + g + 2));        \
             __builtin_amdgcn_sched_barrier(0);                                                   \
-            if (g + 1 < (NBLK))                                                                  \
-                DSS_PK_STEP4(acc, GP[g & 1], GP[(g + 1) & 1], GX[(g + 1) % 3], DSS_PGB_WLO(g + 1, G0), DSS_PGB_WHI(g + 1, G0)); \
-            else                                                                                 \
-                DSS_PK_ADD4(acc, GP[g & 1]);                                                     \
+            DSS_PK_MUL4(PS[g], RX[g % 3], RW[g].lo, RW[g].hi);                                   \
             __builtin_amdgcn_sched_barrier(0);                                                   \
+            RW[g] = *reinterpret_cast<const f32x4 *>(wq + (wo + (unsigned)((GN) + g) * 1024u));  \
         }                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+// the sums of a stage: one dependent chain, input order
+#define DSS_PR_ADD(NBK)                                                                          \
+    {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < (NBK); ++g) DSS_PK_ADD4(acc, PS[g]);               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+// hand the running sums to the other relay wave / take them over (gb_flag = 8 * sample number + stages done)
+#define DSS_PR_PUBLISH(V)                                                                        \
+    {                                                                                            \
+        *reinterpret_cast<f32x2 *>(&L.gb_acc[lane][0]) = acc;                                    \
+        __hip_atomic_store(&L.gb_flag, (V), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     \
+    }
+#define DSS_PR_AWAIT(V)                                                                          \
+    {                                                                                            \
+        while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (V)) \
+            ;                                    /* tight poll: one LDS round trip per iteration is pause enough */ \
+        acc = *reinterpret_cast<const f32x2 *>(&L.gb_acc[lane][0]);                              \
     }
 
 // wave 7: fold the sampled excitation into the signal history and emit the PCM sample (lpcnet_synthesize_tail_impl);
@@ -406,20 +423,18 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
     const float rbz = m.gru_a_rbias[unit], rbr = m.gru_a_rbias[NA + unit], rbh = m.gru_a_rbias[2 * NA + uh];
     const float dgz = m.gru_a_diag[unit], dgr = m.gru_a_diag[NA + unit], dgh = m.gru_a_diag[2 * NA + uh];
     const f32x2 rbh2 = {rbh, rbh}, dgh2 = {dgh, dgh};
-    // dual-FC constants of tree node `tid` (waves 0..3): fw[j] = (layer 0 weight of input j, layer 1 weight of input j)
-    f32x2 fw[HAS_FC ? NB : 1];
+    // dual-FC constants of tree node `tid` (waves 0..3).  The node's 32 weights are not kept: they are loaded once per
+    // sample, after the h chain, into registers that are free by then (m.fc_w_pair: (layer 0, layer 1) weight of input j
+    // side by side) -- these waves have no register to spare between barriers D and C.
     float fb0 = 0, fb1 = 0, ff0 = 0, ff1 = 0;
     if constexpr (HAS_FC) {
         const int node = tid;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            fw[j].x = m.fc_w[(size_t)node * 2 * NB + j];
-            fw[j].y = m.fc_w[(size_t)node * 2 * NB + NB + j];
-        }
         fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
         ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
     }
-    const float u2l_c = L.ulaw2lin[(HAS_FC ? 128 + tid : tid - 256) & 255];   // this lane's excitation candidate (waves 0, 1, 5)
+    // speculation: the quarter of the 256 candidates this wave covers between B and C, or -1 (quarter 0: wave 6)
+    const int myq = wave == 1 ? 3 : wave == 4 ? 2 : wave == 5 ? 1 : -1;
+    const float u2l_c = L.ulaw2lin[(myq * 64 + lane) & 255];     // this lane's excitation candidate
     const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
     const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;     // wave-uniform (kernel argument)
     unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
@@ -545,8 +560,16 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
                 DSS_PH_CHAIN(L.state_a[cur ^ 1])                     // next sample's h chain, under GRU B
-                if (wave == 5 || wave < 2)                           // candidates 64..127 (wave 5), 128..255 (waves 0, 1); wave 6: 0..63
-                    dss_pair_speculate(L, HAS_FC ? 128 + tid : tid - 256, u2l_c);
+                if (myq >= 0) dss_pair_speculate(L, myq * 64 + lane, u2l_c);
+                f32x4 fwq[HAS_FC ? NB / 2 : 1];                      // fwq[k] = weights of inputs 2k, 2k+1, each as (layer 0, layer 1)
+                if constexpr (HAS_FC) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsigned fo = (unsigned)tid * 16;
+                    asm volatile("" : "+v"(fo));                     // a new offset as far as the compiler knows: the loads stay here
+                    const char *fp = reinterpret_cast<const char *>(m.fc_w_pair);    // scalar base + 32-bit lane offset
+#pragma unroll
+                    for (int k = 0; k < NB / 2; ++k) fwq[k] = *reinterpret_cast<const f32x4 *>(fp + (fo + (unsigned)k * DSS_FC_OUT * 16));
+                }
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
@@ -560,7 +583,7 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
 #pragma unroll
                     for (int j4 = 0; j4 < NB / 4; ++j4) {
                         f32x2 ft[8];
-                        DSS_PK_FC4(s0, s1, ft, bj[j4], fw[4 * j4], fw[4 * j4 + 1], fw[4 * j4 + 2], fw[4 * j4 + 3]);
+                        DSS_PK_FC4(s0, s1, ft, bj[j4], fwq[2 * j4].lo, fwq[2 * j4].hi, fwq[2 * j4 + 1].lo, fwq[2 * j4 + 1].hi);
                     }
                     f32x2 t1, t2;
                     dss_tanh_pk2(L.tansig, s0, s1, t1, t2);
@@ -626,10 +649,6 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
     for (int k = tid * 4; k < m.hblk_floats; k += 512 * 4)
         *reinterpret_cast<f32x4 *>(&hblk_lds[k]) = *reinterpret_cast<const f32x4 *>(&m.hblk[k]);
     for (int k = tid; k < NB * NB3; k += 512) L.gb_wrec[k] = m.gru_b_w_rec[k];
-    for (int k = tid; k < NB3 * PGBL; k += 512) {
-        const int row = k / PGBL, j = k - row * PGBL;
-        L.gb_wl[row * PGL_STRIDE + j] = m.gb_w_lane[(size_t)(PGB6 + PGB7 + j) * 64 + row];
-    }
     if (tid < 201) L.tansig[tid] = m.tansig[tid];
     if (tid < 256) L.ulaw2lin[tid] = m.ulaw2lin[tid];
     __syncthreads();
@@ -640,18 +659,15 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
         dss_pair_role_a<TRACE, STAMP, Z, false>(L, hblk_lds, m, b, n_frames, plan, tid, wave, lane);
     } else if (wave == 6) {
         // =====================================================================================================
-        // role B1: GRU B over inputs 0..PGB6-1, lane = row (0..15 z, 16..31 r, 32..47 h), both utterances per lane
+        // role B1: GRU B, the odd stages of the relay (lane = row: 0..15 z, 16..31 r, 32..47 h; both utterances per lane)
         // =====================================================================================================
-        f32x2 WB[PGB6 / 2];
+        f32x4 RW[PR6];                               // weights of this wave's next stage (stage 1 to begin with)
 #pragma unroll
-        for (int j = 0; j < PGB6 / 2; ++j) {
-            WB[j].x = m.gb_w_lane[(size_t)(2 * j) * 64 + lane];
-            WB[j].y = m.gb_w_lane[(size_t)(2 * j + 1) * 64 + lane];
-        }
-        const int row = lane < NB3 ? lane : 0;
+        for (int g = 0; g < PR6; ++g)
+            RW[g] = *reinterpret_cast<const f32x4 *>(m.gb_w_quad + ((size_t)(DSS_PR_G0(1) + g) * 64 + lane) * 4);
         __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
-        const float gbb0 = m.gru_b_bias[row];
         const float u2l_c = L.ulaw2lin[lane];
+        unsigned long long relay6 = 0, atc6 = 0, t6 = 0;   // diagnostic build: barrier B to this wave's last hand-over / to its arrival at C
         for (int jn = 0; jn < plan.n_jobs; ++jn) {
             const PairJob job = dss_pair_job(plan, jn);
             dss_pair_job_init(L, b, job, tid);
@@ -660,20 +676,32 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
             __syncthreads();                                             // job barrier 1
             for (int f = 0; f < n_frames; ++f) {
                 if (job.fc0 + f < DSS_FEATURES_DELAY) continue;
-                const f32x2 gbc = {b.frame_out[((size_t)job.ua * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row],
-                                   b.frame_out[((size_t)job.ub * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row]};
                 for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
-                    f32x2 acc = gbb0 + gbc;                                                 // compute_gruB
+                    f32x2 acc;                                                              // (the chain starts and ends on wave 7)
                     ++seq;
                     if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
                     __syncthreads();                                                        // barrier B
                     const char *an = reinterpret_cast<const char *>(L.state_a[cur ^ 1]);
-                    const char *wl = nullptr;                        // (no LDS-resident weights in this wave's part)
-                    DSS_PGB_HEAD(PGB6 / 4)
-                    DSS_PGB_RUN(PGB6 / 4, PGB6 / 4)
-                    *reinterpret_cast<f32x2 *>(&L.gb_acc[lane][0]) = acc;
-                    __hip_atomic_store(&L.gb_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (STAMP) t6 = __builtin_readcyclecounter();
+                    unsigned wo = (unsigned)lane * 16;
+                    asm volatile("" : "+v"(wo));             // a new offset as far as the compiler knows: the weight loads stay in the loop
+                    const char *wq = reinterpret_cast<const char *>(m.gb_w_quad);    // scalar base + 32-bit lane offset
+                    f32x2 PS[PR6][4];
+                    DSS_PR_MUL(PR6, DSS_PR_G0(1), DSS_PR_G0(3))
+                    DSS_PR_AWAIT(seq * 8 + 1)
+                    DSS_PR_ADD(PR6)
+                    DSS_PR_PUBLISH(seq * 8 + 2)
+                    DSS_PR_MUL(PR6, DSS_PR_G0(3), DSS_PR_G0(5))
+                    DSS_PR_AWAIT(seq * 8 + 3)
+                    DSS_PR_ADD(PR6)
+                    DSS_PR_PUBLISH(seq * 8 + 4)
+                    DSS_PR_MUL(PR6, DSS_PR_G0(5), DSS_PR_G0(1))
+                    DSS_PR_AWAIT(seq * 8 + 5)
+                    DSS_PR_ADD(PR6)
+                    DSS_PR_PUBLISH(seq * 8 + 6)
+                    if (STAMP) relay6 += __builtin_readcyclecounter() - t6;
                     dss_pair_speculate(L, lane, u2l_c);          // this wave is idle from here to barrier B: candidates 0..63
+                    if (STAMP) atc6 += __builtin_readcyclecounter() - t6;
                     __syncthreads();                                                        // barrier C
                     __syncthreads();                                                        // barrier D
                     cur ^= 1;
@@ -682,23 +710,23 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
             __syncthreads();                                                                // final barrier of the job
             __syncthreads();                                                                // job barrier 2
         }
+        if (STAMP && lane == 0 && b.trace_pcm && gridDim.x == 1) { b.trace_pcm[65] = (float)relay6; b.trace_pcm[66] = (float)atc6; }
     } else {
         // =====================================================================================================
-        // role B2 + S (wave 7): GRU B inputs PGB6..383 and gates (both utterances per lane); scalar recurrences with
+        // role B2 + S (wave 7): GRU B, the even stages of the relay and the gates (both utterances per lane); scalar recurrences with
         // utterance A in lanes 0..15 and utterance B in lanes 16..31
         // =====================================================================================================
-        f32x2 WB[PGB7 / 2];
+        f32x4 RW[PR7];                               // weights of this wave's next stage (stage 0 to begin with)
 #pragma unroll
-        for (int j = 0; j < PGB7 / 2; ++j) {
-            WB[j].x = m.gb_w_lane[(size_t)(PGB6 + 2 * j) * 64 + lane];
-            WB[j].y = m.gb_w_lane[(size_t)(PGB6 + 2 * j + 1) * 64 + lane];
-        }
+        for (int g = 0; g < PR7; ++g)
+            RW[g] = *reinterpret_cast<const f32x4 *>(m.gb_w_quad + ((size_t)(DSS_PR_G0(0) + g) * 64 + lane) * 4);
         const int row = lane < NB3 ? lane : 0;
         __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
+        const float gbb0 = m.gru_b_bias[row];
         const float gbb1 = m.gru_b_bias[NB3 + row];
         const int hb = (lane >> 4) & 1, hl = lane & (DSS_LPC_ORDER - 1);
         unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
-        unsigned long long t_prev = 0;
+        unsigned long long t_prev = 0, relay7 = 0, atc7 = 0;   // barrier B to the end of the chain / to this wave's arrival at C (diagnostic build)
         for (int jn = 0; jn < plan.n_jobs; ++jn) {
             const PairJob job = dss_pair_job(plan, jn);
             const int my_utt = hb ? job.ub : job.ua;                 // uniform calls: row == decoder slot
@@ -736,6 +764,8 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
                 }
                 const float *fo = b.frame_out + ((size_t)my_utt * n_frames + f) * DSS_COND_STRIDE;
                 lpc_lane = fo[3 * NA + NB3 + hl];
+                const f32x2 gbc = {b.frame_out[((size_t)job.ua * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row],
+                                   b.frame_out[((size_t)job.ub * n_frames + f) * DSS_COND_STRIDE + 3 * NA + row]};
                 for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
                     if (STAMP) t_prev = __builtin_readcyclecounter();
                     if (!have_spec) {        // first sample of the call: prediction and indices computed directly
@@ -781,14 +811,27 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
                     const f32x2 sb_old = *reinterpret_cast<const f32x2 *>(&L.state_b[lane & (NB - 1)][0]);   // the h lanes' own unit
                     __syncthreads();                                                        // barrier B
                     if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[2] += t - t_prev; t_prev = t; }
-                    const char *an = reinterpret_cast<const char *>(L.state_a[cur ^ 1]) + PGB6 * 8;
-                    const char *wl = reinterpret_cast<const char *>(L.gb_wl + row * PGL_STRIDE);
-                    DSS_PGB_HEAD(PGB7 / 4)                           // the first state pairs of its part, under the wait
-                    __builtin_amdgcn_sched_barrier(0);
-                    while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
-                        ;                                    // tight poll: one LDS round trip per iteration is pause enough
-                    f32x2 acc = *reinterpret_cast<const f32x2 *>(&L.gb_acc[lane][0]);
-                    DSS_PGB_RUN((PGB7 + PGBL) / 4, PGB7 / 4)
+                    const char *an = reinterpret_cast<const char *>(L.state_a[cur ^ 1]);
+                    unsigned wo = (unsigned)lane * 16;
+                    asm volatile("" : "+v"(wo));             // a new offset as far as the compiler knows: the weight loads stay in the loop
+                    const char *wq = reinterpret_cast<const char *>(m.gb_w_quad);    // scalar base + 32-bit lane offset
+                    f32x2 PS[PR7][4];
+                    f32x2 acc = gbb0 + gbc;                                                 // compute_gruB
+                    DSS_PR_MUL(PR7, DSS_PR_G0(0), DSS_PR_G0(2))
+                    DSS_PR_ADD(PR7)
+                    DSS_PR_PUBLISH(seq * 8 + 1)
+                    DSS_PR_MUL(PR7, DSS_PR_G0(2), DSS_PR_G0(4))
+                    DSS_PR_AWAIT(seq * 8 + 2)
+                    DSS_PR_ADD(PR7)
+                    DSS_PR_PUBLISH(seq * 8 + 3)
+                    DSS_PR_MUL(PR7, DSS_PR_G0(4), DSS_PR_G0(6))
+                    DSS_PR_AWAIT(seq * 8 + 4)
+                    DSS_PR_ADD(PR7)
+                    DSS_PR_PUBLISH(seq * 8 + 5)
+                    DSS_PR_MUL(PR7, DSS_PR_G0(6), DSS_PR_G0(0))
+                    DSS_PR_AWAIT(seq * 8 + 6)
+                    DSS_PR_ADD(PR7)
+                    if (STAMP) { asm volatile("" : "+v"(acc)); relay7 += __builtin_readcyclecounter() - t_prev; }
                     {   // gates: lanes 0..15 z, 16..31 r, 32..47 h.  r and z travel up to their unit's h lane with gfx950's
                         // row/half swaps (VALU); the new state is formed in the h lanes.  Only the first result of a swap
                         // is used, with distinct operands (see lpcnet_sample.hip).
@@ -813,6 +856,7 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
                         if (lane >= 2 * NB && lane < NB3)
                             *reinterpret_cast<f32x2 *>(&L.state_b[lane - 2 * NB][0]) = z_for_h * sb_old + (1 - z_for_h) * hh;
                     }
+                    if (STAMP) atc7 += __builtin_readcyclecounter() - t_prev;
                     __syncthreads();                                                        // barrier C
                     if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
                     __syncthreads();                                                        // barrier D
@@ -852,7 +896,10 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
             __syncthreads();                                                                // job barrier 2
         }
         if (STAMP && lane == 0 && b.trace_pcm)          // diagnostic build only
+        {
             for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)(plan.u0 >> 1) * 6 + k] = (float)stamp_acc[k];
+            if (gridDim.x == 1) { b.trace_pcm[64] = (float)relay7; b.trace_pcm[67] = (float)atc7; }
+        }
     }
 }
 

@@ -3,7 +3,7 @@
     python tools/ab_time.py path/to/a.so path/to/b.so ...
 
 Each library is timed in its own child process (the exported symbols would clash otherwise) through the C ABI only:
-batch 256 x 100 frames, sample-kernel time from the library's own HIP events."""
+batch 256 x 100 frames (AB_BATCH=n: another batch size), sample-kernel time from the library's own HIP events."""
 import ctypes as C
 import os
 import subprocess
@@ -29,12 +29,12 @@ def child(path):
     L.dss_lpcnet_load_model.argtypes = [C.c_char_p, C.c_size_t]
     blob = synthetic_blob(0)
     assert L.dss_lpcnet_load_model(blob, len(blob)) == 0
-    B, F = 256, 100
+    B, F = int(os.environ.get("AB_BATCH", "256")), 100         # AB_BATCH=1024: the two-utterances-per-workgroup kernel
     feats = torch.from_numpy(np.stack([synthetic_features(b, F) for b in range(B)])).cuda()
     out = torch.empty((B, F * 160), dtype=torch.int16, device="cuda")
     h = L.dss_lpcnet_batch_create(B, F)
     ms = []
-    for it in range(6):
+    for it in range(6 if B <= 256 else 4):
         L.dss_lpcnet_batch_reset(h, -1)
         L.dss_lpcnet_batch_enable_timing(h, 1)
         assert L.dss_lpcnet_batch_synthesize_dev(h, feats.data_ptr(), B, F, 20, out.data_ptr(), None) == 0

@@ -24,6 +24,9 @@ st = raw[: B * 6].reshape(B, 6) / n
 print("wave 7 (scalar role) view, cycles per sample, mean over utterances:")
 print("  " + "  ".join(f"{names[k]}={st[:, k].mean():8.1f}" for k in range(6)), " total", st.sum(axis=1).mean())
 print("  min/max total over utterances:", st.sum(axis=1).min(), st.sum(axis=1).max())
+if MODE == 2 and B == 1:                                   # one workgroup: the relay waves' own stamps inside B..C
+    print(f"  GRU B relay, from barrier B: wave 6 hands over for the last time at {raw[65] / n:.1f} and reaches C at {raw[66] / n:.1f}, "
+          f"wave 7 ends the chain at {raw[64] / n:.1f} and reaches C at {raw[67] / n:.1f}")
 rawA = np.empty((F * 160,), np.float32)
 chunks = []
 for k in range((B * 48 + rawA.size - 1) // rawA.size):
