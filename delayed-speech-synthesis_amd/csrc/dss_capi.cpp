@@ -1263,6 +1263,19 @@ extern "C" int dss_selftest_exp10(const float *x, const float *comp, float *out,
     return rc;
 }
 
+extern "C" int dss_selftest_lin2ulaw(unsigned start_bits, unsigned stride, long n, unsigned char *out)
+{
+    if (!out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    unsigned char *dout = nullptr;
+    rc = dev_alloc<unsigned char>((size_t)n, &dout);
+    if (!rc) rc = dss_launch_lin2ulaw_selftest(start_bits, stride, n, dout, 0);
+    if (!rc && hipMemcpy(out, dout, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = DSS_ENODEV;
+    hipFree(dout);
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // HGA
 // ------------------------------------------------------------------------------------------------------

@@ -146,6 +146,7 @@ int dss_pair_fits(const DssModelDev &m);
 int dss_launch_sample_network_generic(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
                                       int trace, hipStream_t s);
 int dss_launch_exp10_selftest(const float *d_x, const float *d_comp, float *d_out, long n, hipStream_t s);
+int dss_launch_lin2ulaw_selftest(unsigned start, unsigned stride, long n, unsigned char *d_out, hipStream_t s);
 int dss_launch_lpcnet_reset(const DssModelDev &m, DssBatchDev &b, int utt, hipStream_t s);
 
 // ---- speech-segment gate (speech_gate.hip) ---------------------------------------------------------------

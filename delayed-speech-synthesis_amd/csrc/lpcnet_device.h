@@ -91,7 +91,7 @@ __device__ __forceinline__ int dss_lin2ulaw(float x)
     u = __builtin_fmaf(r, rc, q0);
     u = 128 + u;
     u = __builtin_fminf(__builtin_fmaxf(u, 0.f), 255.f);
-    return (int)floorf(u + .5f);
+    return (int)floorf(u + .5f);            // (v_cvt_rpi_i32_f32 does this in one instruction and passes the sweep, but as inline asm it measured 0.3 % slower)
 }
 
 // kiss99.c

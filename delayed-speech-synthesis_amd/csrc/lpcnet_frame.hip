@@ -215,6 +215,21 @@ int dss_launch_exp10_selftest(const float *d_x, const float *d_comp, float *d_ou
     return DSS_OK;
 }
 
+// ---- self-test of lin2ulaw as the sample kernels evaluate it (lpcnet_device.h): out[i] = lin2ulaw of the fp32 value whose
+// bit pattern is start + i * stride.  tests/test_gpu_lpcnet.py compares a strided sweep of all 2^32 patterns with the C form.
+__global__ void lin2ulaw_selftest_kernel(unsigned start, unsigned stride, long n, unsigned char *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (unsigned char)dss_lin2ulaw(__uint_as_float(start + (unsigned)i * stride));
+}
+
+int dss_launch_lin2ulaw_selftest(unsigned start, unsigned stride, long n, unsigned char *d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(lin2ulaw_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, start, stride, n, d_out);
+    DSS_HIP_CHECK(hipGetLastError());
+    return DSS_OK;
+}
+
 // ---- final stage: delayed lpc into frame_out, persistent state update ------------------------------------
 __global__ void __launch_bounds__(128)
 frame_finish_kernel(DssBatchDev b, int n_frames)

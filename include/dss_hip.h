@@ -160,6 +160,9 @@ int dss_lpcnet_batch_force_excitation(dss_lpcnet_batch *b, const unsigned char *
 /* Self-test of the only transcendental evaluated on the device on this path: out[i] = (float)(pow(10.0, x[i]) *
  * comp[i]), the expression of freq.c lpc_from_cepstrum (host buffers).  See DESIGN.md section 2. */
 int dss_selftest_exp10(const float *x, const float *comp, float *out, long n);
+/* Self-test of the device's lin2ulaw (xiph common.h; evaluated in a shorter instruction sequence):
+ * out[i] = lin2ulaw(x) for the fp32 x whose bit pattern is start_bits + i * stride (wrapping), i < n (host buffer). */
+int dss_selftest_lin2ulaw(unsigned start_bits, unsigned stride, long n, unsigned char *out);
 /* Host-only (no GPU): lays the model out for the CU-resident sample kernel and walks every lane's z, r and h block lists
  * through that layout as the kernel indexes it.  info[8]: fast_path (0/1/2 as in dss_lpcnet_model_info), zr blocks max,
  * h blocks max, LDS bytes, register slots per gate on waves 4-5, tail blocks, mismatching rows, out-of-range reads. */

@@ -123,6 +123,15 @@ static int lin2ulaw(float x)         /* xiph common.h */
 
 /* exported for the known-answer tests */
 int oracle_lin2ulaw(float x) { return lin2ulaw(x); }
+/* lin2ulaw of the fp32 values with bit patterns start + i * stride (the sweep of the device self-test) */
+void oracle_lin2ulaw_sweep(unsigned start, unsigned stride, long n, unsigned char *out)
+{
+    for (long i = 0; i < n; ++i) {
+        union { unsigned u; float f; } v;
+        v.u = start + (unsigned)i * stride;
+        out[i] = (unsigned char)lin2ulaw(v.f);
+    }
+}
 float oracle_ulaw2lin(float u) { return ulaw2lin(u); }
 
 oracle_lpcnet_model *oracle_lpcnet_model_load(const void *blob, size_t len)

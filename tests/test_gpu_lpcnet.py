@@ -453,6 +453,32 @@ def test_device_pow_equals_host_libm_after_the_float_rounding(oracle):
     assert bad.size == 0, (bad.size, x[bad[:5]], got[bad[:5]], want[bad[:5]])
 
 
+def test_device_lin2ulaw_equals_the_c_form_on_a_sweep_of_all_bit_patterns(oracle):
+    """csrc/lpcnet_device.h evaluates xiph's lin2ulaw() (common.h; used by lpcnet_synthesize_tail_impl for the two mu-law
+    indices of every sample, here inside the speculation) in a shorter instruction sequence: constant division as a product
+    with two fused corrections, max/min clamp, float rounding.  tools/verify/lin2ulaw_exhaustive.c proves a C restatement
+    of that sequence equal to the C form for every fp32 input; this closes the loop on the device itself: every 97th bit
+    pattern of the whole 2^32 range (44 M values, NaNs skipped: (int) of a NaN is undefined in the C source), plus every
+    pattern of the two binades around +-32768 where the PCM values live."""
+    import ctypes
+    from dss_amd import _lib
+    L = _lib.require_gpu()
+    oracle.lib.oracle_lin2ulaw_sweep.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_long, ctypes.c_void_p]
+    oracle.lib.oracle_lin2ulaw_sweep.restype = None
+    sweeps = [(0, 97, (1 << 32) // 97)]
+    for sign in (0, 0x80000000):
+        sweeps.append((sign | 0x46000000, 1, 1 << 24))            # 8192 <= |x| < 32768 (2 binades), every value
+    for start, stride, n in sweeps:
+        got = np.empty(n, np.uint8)
+        want = np.empty(n, np.uint8)
+        _lib.check(L.dss_selftest_lin2ulaw(start, stride, n, got.ctypes.data))
+        oracle.lib.oracle_lin2ulaw_sweep(start, stride, n, want.ctypes.data)
+        bits = (np.uint32(start) + np.arange(n, dtype=np.uint32) * np.uint32(stride))
+        ok = ~np.isnan(bits.view(np.float32))
+        bad = np.nonzero((got != want) & ok)[0]
+        assert bad.size == 0, (start, stride, bad.size, bits[bad[:5]], got[bad[:5]], want[bad[:5]])
+
+
 def test_void_synthesize_never_aborts(model):
     """cLPCNet.pxd:13 has no error channel: a bad call zero-fills the frame and is counted; the state keeps working."""
     import LPCNet
