@@ -683,6 +683,8 @@ struct dss_lpcnet_batch {
     short *d_pcm = nullptr;
     int *d_slots = nullptr;       // [max_utts] slot list of a ragged call
     int *d_counts = nullptr;      // [max_utts] frame counts of a ragged call
+    int *d_order = nullptr;       // [max_utts] dispatch order of a ragged call: rows by decreasing frame count
+    std::vector<int> h_order;     //   its host copy (kept until the async copy has been issued from it)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     double ms_sum[2] = {0, 0};
     int ms_n = 0;
@@ -724,6 +726,7 @@ extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frame
     rc |= dev_alloc<short>(B * F * DSS_FRAME_SIZE, &b->d_pcm);
     rc |= dev_alloc<int>(B, &b->d_slots);
     rc |= dev_alloc<int>(B, &b->d_counts);
+    rc |= dev_alloc<int>(B, &b->d_order);
     for (int i = 0; i < 3; ++i) rc |= (hipEventCreate(&b->ev[i]) != hipSuccess);
     if (rc) {
         dss_set_error("device allocation failed for batch %d x %d", max_utts, max_frames);
@@ -741,7 +744,7 @@ extern "C" void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b)
     DssBatchDev &d = b->d;
     void *ptrs[] = {d.gru_a_state, d.gru_b_state, d.last_sig, d.last_exc, d.deemph, d.rng, d.frame_count, d.conv1_mem,
                     d.conv2_mem, d.old_lpc, d.in_buf, d.c1_buf, d.c2_buf, d.d1_buf, d.cond_buf, d.lpc_buf, d.frame_out,
-                    d.fc0, d.trace_exc, d.trace_pcm, d.trace_logits, (void *)d.force_exc, b->d_feat, b->d_pcm, b->d_slots, b->d_counts};
+                    d.fc0, d.trace_exc, d.trace_pcm, d.trace_logits, (void *)d.force_exc, b->d_feat, b->d_pcm, b->d_slots, b->d_counts, b->d_order};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int i = 0; i < 3; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
     release_model(b->host_model);
@@ -905,14 +908,14 @@ extern "C" int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float 
     int rc = check_batch_shape(b, n_utts, n_frames, feat_stride);
     if (rc) return rc;
     DSS_HIP_CHECK(hipSetDevice(b->device));
-    b->d.slot_of = nullptr; b->d.count_of = nullptr;
+    b->d.slot_of = nullptr; b->d.count_of = nullptr; b->d.row_of = nullptr;
     return run_batch(b, d_features, n_utts, n_frames, feat_stride, d_pcm, (hipStream_t)hip_stream);
 }
 
 // Validate and upload the slot list / frame counts of a ragged call (either may be NULL).
 static int stage_ragged(dss_lpcnet_batch *b, const int *slots, const int *counts, int n_utts, int n_frames, hipStream_t s)
 {
-    b->d.slot_of = nullptr; b->d.count_of = nullptr;
+    b->d.slot_of = nullptr; b->d.count_of = nullptr; b->d.row_of = nullptr;
     if (slots) {
         std::string seen((size_t)b->d.max_utts, 0);
         for (int i = 0; i < n_utts; ++i) {
@@ -928,6 +931,13 @@ static int stage_ragged(dss_lpcnet_batch *b, const int *slots, const int *counts
             if (counts[i] < 0 || counts[i] > n_frames) { dss_set_error("row %d: %d frames outside [0, %d]", i, counts[i], n_frames); return DSS_EINVAL; }
         DSS_HIP_CHECK(hipMemcpyAsync(b->d_counts, counts, sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
         b->d.count_of = b->d_counts;
+        // Dispatch order: workgroups start in grid order, so the longest rows go first whatever order the caller used
+        // (and the pair kernel's two rows of a workgroup are neighbours in length).  Results do not depend on it.
+        b->h_order.resize((size_t)n_utts);
+        for (int i = 0; i < n_utts; ++i) b->h_order[i] = i;
+        std::stable_sort(b->h_order.begin(), b->h_order.end(), [&](int x, int y) { return counts[x] > counts[y]; });
+        DSS_HIP_CHECK(hipMemcpyAsync(b->d_order, b->h_order.data(), sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
+        b->d.row_of = b->d_order;
     }
     return DSS_OK;
 }
@@ -1070,7 +1080,7 @@ static int level1_graph_frame(LPCNetState *st, const float *features, short *out
         hipGraph_t graph = nullptr;
         DSS_HIP_CHECK(hipStreamBeginCapture(st->stream, hipStreamCaptureModeThreadLocal));
         hipError_t e1 = hipMemcpyAsync(b->d_feat, st->h_feat, DSS_NB_FEATURES * sizeof(float), hipMemcpyHostToDevice, st->stream);
-        b->d.slot_of = nullptr; b->d.count_of = nullptr;
+        b->d.slot_of = nullptr; b->d.count_of = nullptr; b->d.row_of = nullptr;
         const int rc = e1 == hipSuccess ? run_batch(b, b->d_feat, 1, 1, DSS_NB_FEATURES, b->d_pcm, st->stream) : DSS_ENODEV;
         hipError_t e2 = hipMemcpyAsync(st->h_pcm, b->d_pcm, DSS_FRAME_SIZE * sizeof(short), hipMemcpyDeviceToHost, st->stream);
         hipError_t e3 = hipStreamEndCapture(st->stream, &graph);             // always ends the capture

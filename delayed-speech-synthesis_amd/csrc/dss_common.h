@@ -124,6 +124,7 @@ struct DssBatchDev {
     // ragged / slot-indexed calls (NULL = row i continues slot i, every row has n_frames frames)
     const int *slot_of;   // [n] decoder slot continued by row i of the call
     const int *count_of;  // [n] frames of row i (<= n_frames of the call; 0 leaves the slot untouched)
+    const int *row_of;    // [n] ragged calls with counts: row handled by the k-th workgroup (slot), longest rows first
     // trace (optional)
     float *trace_exc, *trace_pcm;   // [B][F*160]
     // teacher forcing (tests; honoured by the TRACE instantiations only): sample k of row u takes the excitation

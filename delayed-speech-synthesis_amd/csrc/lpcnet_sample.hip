@@ -367,8 +367,9 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     __shared__ __attribute__((aligned(16))) SampleLds L;
     extern __shared__ __attribute__((aligned(16))) float hblk_lds[];       // h-gate block records (size per model)
     static_assert(sizeof(SampleLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
-    const int utt = blockIdx.x;                                            // row of this call (scratch, features, PCM)
     constexpr bool RG = RAGGED || TRACE;
+    // row of this call (scratch, features, PCM): ragged calls with counts start their longest rows first (b.row_of)
+    const int utt = (RG && b.row_of) ? __builtin_amdgcn_readfirstlane(b.row_of[blockIdx.x]) : (int)blockIdx.x;
     const int slot = (RG && b.slot_of) ? b.slot_of[utt] : utt;                     // decoder state it continues
     const int nf = (RG && b.count_of) ? min(b.count_of[utt], n_frames) : n_frames; // its own frame count
     const int tid = threadIdx.x;
@@ -632,10 +633,10 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
                               int pair, hipStream_t s)
 {
     if (!m.fast_ok || trace >= 16) return dss_launch_sample_network_generic(m, b, n_utts, n_frames, d_pcm, trace & 15, s);
-    // Uniform calls with more utterances than the chip has CUs run two utterances per workgroup (lpcnet_sample_pair.hip:
-    // the same roles with the utterances as the halves of packed fp32 instructions); with a CU per utterance the
-    // one-utterance form below is faster.  pair: 0 = this rule, -1 = never, 2 = always (tests, A/B timing).
-    if (pair >= 0 && trace <= 2 && !b.slot_of && !b.count_of && dss_pair_fits(m) &&
+    // Calls with more rows than the chip has CUs run two utterances per workgroup (lpcnet_sample_pair.hip: the same
+    // roles with the utterances as the halves of packed fp32 instructions); with a CU per utterance the one-utterance
+    // form below is faster.  pair: 0 = this rule, -1 = never, 2 = always (tests, A/B timing).
+    if (pair >= 0 && trace <= 2 && !(trace == 2 && (b.slot_of || b.count_of)) && dss_pair_fits(m) &&
         (pair == 2 || (!trace && n_utts > 128 && n_utts > dss_cu_count())))
         return dss_launch_sample_network_pair(m, b, n_utts, n_frames, d_pcm, trace, s);
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;

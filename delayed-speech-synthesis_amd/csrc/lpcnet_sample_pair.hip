@@ -261,29 +261,44 @@ __device__ __forceinline__ void dss_pair_speculate(PairLds &L, int cand, float u
     L.spec_tab_idx[1][cand] = (unsigned short)(su1 | (pu1 << 8));
 }
 
-// what a workgroup runs: utterance rows ua and ub of the call (ub == ua and !has_b: a single utterance, the B halves
-// compute a copy that is never stored)
-struct PairJob { int ua, ub; bool has_b; int fc0; };
+// what a workgroup runs: rows ua and ub of the call (frames, PCM), continuing decoder slots sa and sb, frames [f0, f1)
+// (ub == ua and !has_b: a single utterance, the B halves compute a copy that is never stored)
+struct PairJob { int ua, ub, sa, sb; bool has_b; int fc0, f0, f1; };
 // The two utterances of a workgroup run as one packed job when both exist and have the same number of silent frames
 // ahead of them (frame_count < FEATURES_DELAY: fresh decoders); otherwise one after the other, each with its copy in
-// the B halves.  All fields are wave-uniform.
-struct PairPlan { int u0, fa, fb, n_jobs; bool packed; };
-__device__ __forceinline__ PairJob dss_pair_job(const PairPlan &p, int jn)
+// the B halves.  Ragged calls (RAGGED instantiation: rows name their decoder slot and frame count): the packed job covers
+// the frames both rows have, the longer row finishes alone in a second job, which picks its decoder state up from
+// global memory exactly as the next call would.  All fields are wave-uniform.
+struct PairPlan { int u0, u1, fa, fb, n_jobs; bool packed; int sa, sb, nfa, nfb; };
+template <bool RAGGED>
+__device__ __forceinline__ PairJob dss_pair_job(const PairPlan &p, int jn, int n_frames)
 {
-    if (p.n_jobs == 1) return PairJob{p.u0, p.packed ? p.u0 + 1 : p.u0, p.packed, p.fa};
-    return jn == 0 ? PairJob{p.u0, p.u0, false, p.fa} : PairJob{p.u0 + 1, p.u0 + 1, false, p.fb};
+    if constexpr (!RAGGED) {
+        if (p.n_jobs == 1) return PairJob{p.u0, p.packed ? p.u0 + 1 : p.u0, p.u0, p.packed ? p.u0 + 1 : p.u0, p.packed, p.fa, 0, n_frames};
+        return jn == 0 ? PairJob{p.u0, p.u0, p.u0, p.u0, false, p.fa, 0, n_frames}
+                       : PairJob{p.u0 + 1, p.u0 + 1, p.u0 + 1, p.u0 + 1, false, p.fb, 0, n_frames};
+    } else {
+        const PairJob only_a = {p.u0, p.u0, p.sa, p.sa, false, p.fa, 0, p.nfa};
+        const PairJob only_b = {p.u1, p.u1, p.sb, p.sb, false, p.fb, 0, p.nfb};
+        if (!p.packed) return jn == 0 ? only_a : only_b;             // (a lone last row: n_jobs == 1)
+        const int nmin = min(p.nfa, p.nfb);
+        if (jn == 0) return PairJob{p.u0, p.u1, p.sa, p.sb, true, p.fa, 0, nmin};
+        PairJob rest = p.nfa > p.nfb ? only_a : only_b;
+        rest.f0 = nmin;
+        return rest;
+    }
 }
 
 // decoder state of the job's utterances into LDS (all 512 threads), followed by a barrier at the caller
 __device__ __forceinline__ void dss_pair_job_init(PairLds &L, const DssBatchDev &b, const PairJob &j, int tid)
 {
     if (tid < NA) {
-        f32x2 s = {b.gru_a_state[(size_t)j.ua * NA + tid], b.gru_a_state[(size_t)j.ub * NA + tid]};
+        f32x2 s = {b.gru_a_state[(size_t)j.sa * NA + tid], b.gru_a_state[(size_t)j.sb * NA + tid]};
         *reinterpret_cast<f32x2 *>(&L.state_a[0][2 * tid]) = s;
     }
     if (tid < 16) L.state_a[tid >> 3][2 * NA + (tid & 7)] = 0.f;
     if (tid < NB) {
-        f32x2 s = {b.gru_b_state[(size_t)j.ua * NB + tid], b.gru_b_state[(size_t)j.ub * NB + tid]};
+        f32x2 s = {b.gru_b_state[(size_t)j.sa * NB + tid], b.gru_b_state[(size_t)j.sb * NB + tid]};
         *reinterpret_cast<f32x2 *>(&L.state_b[tid][0]) = s;
     }
     if (tid == 0) L.gb_flag = 0;
@@ -396,7 +411,7 @@ __device__ __forceinline__ void dss_pair_job_init(PairLds &L, const DssBatchDev 
 // =====================================================================================================
 // role A: GRU A (+ dual-FC on waves 0..3, + the speculation on waves 0, 1, 5) for the two utterances of the job
 // =====================================================================================================
-template <bool TRACE, bool STAMP, int Z, bool HAS_FC>
+template <bool TRACE, bool STAMP, int Z, bool HAS_FC, bool RAGGED>
 __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, const DssModelDev &m, const DssBatchDev &b,
                                                 int n_frames, const PairPlan plan, int tid, int wave, int lane)
 {
@@ -440,7 +455,7 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
     unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
 
     for (int jn = 0; jn < plan.n_jobs; ++jn) {
-        const PairJob job = dss_pair_job(plan, jn);
+        const PairJob job = dss_pair_job<RAGGED>(plan, jn, n_frames);
         const int ua = job.ua, ub = job.ub, fc0 = job.fc0;
         dss_pair_job_init(L, b, job, tid);
         __syncthreads();                                             // job barrier 0: decoder state in LDS
@@ -450,7 +465,7 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
         DSS_PH_CHAIN(L.state_a[0])                                   // first sample of this call
         __syncthreads();                                             // job barrier 1: L.ah of every unit visible to its z/r lane
 
-        for (int f = 0; f < n_frames; ++f) {
+        for (int f = job.f0; f < job.f1; ++f) {
             if (fc0 + f < DSS_FEATURES_DELAY) continue;              // silent frame: decoder state untouched
             const float *foa = b.frame_out + ((size_t)ua * n_frames + f) * DSS_COND_STRIDE;     // wave-uniform bases
             const float *fob = b.frame_out + ((size_t)ub * n_frames + f) * DSS_COND_STRIDE;
@@ -616,15 +631,15 @@ __device__ __forceinline__ void dss_pair_role_a(PairLds &L, float *hblk_lds, con
             }
         }
         __syncthreads();                                                                // final barrier of the job
-        b.gru_a_state[(size_t)ua * NA + unit] = st.x;
-        if (job.has_b) b.gru_a_state[(size_t)ub * NA + unit] = st.y;
+        b.gru_a_state[(size_t)job.sa * NA + unit] = st.x;
+        if (job.has_b) b.gru_a_state[(size_t)job.sb * NA + unit] = st.y;
         __syncthreads();                                                                // job barrier 2: LDS free for the next job
     }
     if (STAMP && lane == 0 && b.trace_exc)
-        for (int k = 0; k < 8; ++k) b.trace_exc[((size_t)(plan.u0 >> 1) * 6 + wave) * 8 + k] = (float)sa[k];
+        for (int k = 0; k < 8; ++k) b.trace_exc[((size_t)blockIdx.x * 6 + wave) * 8 + k] = (float)sa[k];
 }
 
-template <bool TRACE, bool STAMP, int Z>
+template <bool TRACE, bool STAMP, int Z, bool RAGGED>
 __global__ void __launch_bounds__(512)
 lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames, short *__restrict__ pcm_out)
 {
@@ -636,13 +651,27 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
 
     PairPlan plan;
     {
-        const int u0 = 2 * blockIdx.x, u1 = u0 + 1;
+        int u0 = 2 * blockIdx.x, u1 = u0 + 1;
         const bool has1 = u1 < n_utts;
+        if constexpr (RAGGED) if (b.row_of) {                        // dispatch order: the longest rows first, neighbours in length together
+            u0 = __builtin_amdgcn_readfirstlane(b.row_of[2 * blockIdx.x]);
+            u1 = has1 ? __builtin_amdgcn_readfirstlane(b.row_of[2 * blockIdx.x + 1]) : u0 + 1;
+        }
         const int fa = b.fc0[u0], fb = has1 ? b.fc0[u1] : fa;
         const bool same = min(fa, DSS_FEATURES_DELAY) == min(fb, DSS_FEATURES_DELAY);
-        plan.u0 = u0; plan.fa = __builtin_amdgcn_readfirstlane(fa); plan.fb = __builtin_amdgcn_readfirstlane(fb);
+        plan.u0 = u0; plan.u1 = u1; plan.fa = __builtin_amdgcn_readfirstlane(fa); plan.fb = __builtin_amdgcn_readfirstlane(fb);
         plan.packed = has1 && same;
         plan.n_jobs = (has1 && !same) ? 2 : 1;
+        plan.sa = u0; plan.sb = has1 ? u1 : u0; plan.nfa = plan.nfb = n_frames;
+        if constexpr (RAGGED) {                                      // rows name their decoder slot and frame count
+            const int ub_ = has1 ? u1 : u0;
+            if (b.slot_of) { plan.sa = __builtin_amdgcn_readfirstlane(b.slot_of[u0]); plan.sb = __builtin_amdgcn_readfirstlane(b.slot_of[ub_]); }
+            if (b.count_of) {
+                plan.nfa = __builtin_amdgcn_readfirstlane(min(b.count_of[u0], n_frames));
+                plan.nfb = __builtin_amdgcn_readfirstlane(min(b.count_of[ub_], n_frames));
+            }
+            if (plan.packed && plan.nfa != plan.nfb) plan.n_jobs = 2;    // the longer row finishes alone
+        }
     }
 
     // ---------------- one-time staging into LDS -------------------------------------------------------
@@ -654,9 +683,9 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
     __syncthreads();
 
     if (wave < 4) {
-        dss_pair_role_a<TRACE, STAMP, (Z < 8 ? Z : 8), true>(L, hblk_lds, m, b, n_frames, plan, tid, wave, lane);
+        dss_pair_role_a<TRACE, STAMP, (Z < 8 ? Z : 8), true, RAGGED>(L, hblk_lds, m, b, n_frames, plan, tid, wave, lane);
     } else if (wave < 6) {
-        dss_pair_role_a<TRACE, STAMP, Z, false>(L, hblk_lds, m, b, n_frames, plan, tid, wave, lane);
+        dss_pair_role_a<TRACE, STAMP, Z, false, RAGGED>(L, hblk_lds, m, b, n_frames, plan, tid, wave, lane);
     } else if (wave == 6) {
         // =====================================================================================================
         // role B1: GRU B, the odd stages of the relay (lane = row: 0..15 z, 16..31 r, 32..47 h; both utterances per lane)
@@ -669,12 +698,12 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
         const float u2l_c = L.ulaw2lin[lane];
         unsigned long long relay6 = 0, atc6 = 0, t6 = 0;   // diagnostic build: barrier B to this wave's last hand-over / to its arrival at C
         for (int jn = 0; jn < plan.n_jobs; ++jn) {
-            const PairJob job = dss_pair_job(plan, jn);
+            const PairJob job = dss_pair_job<RAGGED>(plan, jn, n_frames);
             dss_pair_job_init(L, b, job, tid);
             __syncthreads();                                             // job barrier 0
             int cur = 0, seq = 0;
             __syncthreads();                                             // job barrier 1
-            for (int f = 0; f < n_frames; ++f) {
+            for (int f = job.f0; f < job.f1; ++f) {
                 if (job.fc0 + f < DSS_FEATURES_DELAY) continue;
                 for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
                     f32x2 acc;                                                              // (the chain starts and ends on wave 7)
@@ -728,22 +757,23 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
         unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long t_prev = 0, relay7 = 0, atc7 = 0;   // barrier B to the end of the chain / to this wave's arrival at C (diagnostic build)
         for (int jn = 0; jn < plan.n_jobs; ++jn) {
-            const PairJob job = dss_pair_job(plan, jn);
-            const int my_utt = hb ? job.ub : job.ua;                 // uniform calls: row == decoder slot
+            const PairJob job = dss_pair_job<RAGGED>(plan, jn, n_frames);
+            const int my_utt = hb ? job.ub : job.ua;                 // row of the call: features, PCM, traces
+            const int my_slot = hb ? job.sb : job.sa;                // decoder it continues (uniform calls: the row itself)
             const bool owner = hl == 0 && lane < 32 && (hb == 0 || job.has_b);   // the lane that stores its utterance's scalars
             dss_pair_job_init(L, b, job, tid);
             __syncthreads();                                             // job barrier 0
             // signal history and LPC of the current frame, element j of utterance hb in lane 16*hb + j
-            float ls_lane = b.last_sig[(size_t)my_utt * DSS_LPC_ORDER + hl], lpc_lane = 0.f;
-            float deemph = b.deemph[my_utt];
-            int last_exc = b.last_exc[my_utt];
-            DssKiss99 rng = {b.rng[my_utt * 4 + 0], b.rng[my_utt * 4 + 1], b.rng[my_utt * 4 + 2], b.rng[my_utt * 4 + 3]};
+            float ls_lane = b.last_sig[(size_t)my_slot * DSS_LPC_ORDER + hl], lpc_lane = 0.f;
+            float deemph = b.deemph[my_slot];
+            int last_exc = b.last_exc[my_slot];
+            DssKiss99 rng = {b.rng[my_slot * 4 + 0], b.rng[my_slot * 4 + 1], b.rng[my_slot * 4 + 2], b.rng[my_slot * 4 + 3]};
             int cur = 0, seq = 0;
             float pred = 0.f, upd_pred = 0.f;
             int upd_exc = 0, upd_i = 0;
             bool have_spec = false, next_exists = false, upd_pending = false;
             __syncthreads();                                             // job barrier 1
-            for (int f = 0; f < n_frames; ++f) {
+            for (int f = job.f0; f < job.f1; ++f) {
                 short *pcm_a = pcm_out + ((size_t)job.ua * n_frames + f) * DSS_FRAME_SIZE;
                 short *pcm_b = pcm_out + ((size_t)job.ub * n_frames + f) * DSS_FRAME_SIZE;
                 if (job.fc0 + f < DSS_FEATURES_DELAY) {             // lpcnet.c: frame_count <= FEATURES_DELAY -> silence
@@ -795,7 +825,7 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
                     }
                     {   // inputs of the speculation the other waves run between barriers B and C
                         const bool last_of_frame = (i == DSS_FRAME_SIZE - 1);
-                        next_exists = !(last_of_frame && f == n_frames - 1);
+                        next_exists = !(last_of_frame && f == job.f1 - 1);
                         float lp = lpc_lane;
                         if (last_of_frame && next_exists)
                             lp = b.frame_out[((size_t)my_utt * n_frames + f + 1) * DSS_COND_STRIDE + 3 * NA + NB3 + hl];
@@ -884,20 +914,20 @@ lpcnet_sample_pair_kernel(DssModelDev m, DssBatchDev b, int n_utts, int n_frames
             }
             __syncthreads();                                                                // final barrier of the job
             if (lane < NB) {
-                b.gru_b_state[(size_t)job.ua * NB + lane] = L.state_b[lane][0];
-                if (job.has_b) b.gru_b_state[(size_t)job.ub * NB + lane] = L.state_b[lane][1];
+                b.gru_b_state[(size_t)job.sa * NB + lane] = L.state_b[lane][0];
+                if (job.has_b) b.gru_b_state[(size_t)job.sb * NB + lane] = L.state_b[lane][1];
             }
-            if (lane < 32 && (hb == 0 || job.has_b)) b.last_sig[(size_t)my_utt * DSS_LPC_ORDER + hl] = ls_lane;
+            if (lane < 32 && (hb == 0 || job.has_b)) b.last_sig[(size_t)my_slot * DSS_LPC_ORDER + hl] = ls_lane;
             if (owner) {
-                b.deemph[my_utt] = deemph;
-                b.last_exc[my_utt] = last_exc;
-                b.rng[my_utt * 4 + 0] = rng.z; b.rng[my_utt * 4 + 1] = rng.w; b.rng[my_utt * 4 + 2] = rng.jsr; b.rng[my_utt * 4 + 3] = rng.jcong;
+                b.deemph[my_slot] = deemph;
+                b.last_exc[my_slot] = last_exc;
+                b.rng[my_slot * 4 + 0] = rng.z; b.rng[my_slot * 4 + 1] = rng.w; b.rng[my_slot * 4 + 2] = rng.jsr; b.rng[my_slot * 4 + 3] = rng.jcong;
             }
             __syncthreads();                                                                // job barrier 2
         }
         if (STAMP && lane == 0 && b.trace_pcm)          // diagnostic build only
         {
-            for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)(plan.u0 >> 1) * 6 + k] = (float)stamp_acc[k];
+            for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)blockIdx.x * 6 + k] = (float)stamp_acc[k];
             if (gridDim.x == 1) { b.trace_pcm[64] = (float)relay7; b.trace_pcm[67] = (float)atc7; }
         }
     }
@@ -910,12 +940,15 @@ int dss_pair_fits(const DssModelDev &m)
     return m.fast_ok && !m.ext && (size_t)m.hblk_floats * sizeof(float) <= DSS_PAIR_HBLK_BYTES;
 }
 
-// uniform calls only (row i continues decoder slot i, every row has n_frames frames); trace: 0, 1 (excitation / pcm trace
-// and teacher forcing), 2 (phase stamps of the diagnostic build)
+// trace: 0, 1 (excitation / pcm trace and teacher forcing), 2 (phase stamps of the diagnostic build: uniform calls only).
+// Ragged calls (b.slot_of / b.count_of) run the RAGGED instantiation: rows 2k and 2k+1 share a workgroup, so a caller
+// that orders its rows by length (longest first, as the synthesis queue does) pairs rows of near-equal length.
 int dss_launch_sample_network_pair(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm, int trace,
                                    hipStream_t s)
 {
-    if (!dss_pair_fits(m) || b.slot_of || b.count_of) { dss_set_error("pair kernel: model or call shape not supported"); return DSS_EINVAL; }
+    if (!dss_pair_fits(m)) { dss_set_error("pair kernel: model layout not supported"); return DSS_EINVAL; }
+    const bool ragged = b.slot_of || b.count_of;
+    if (ragged && trace == 2) { dss_set_error("phase stamps are taken on uniform calls only"); return DSS_EINVAL; }
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
     const bool z10 = m.zr_cap <= 10;
     static std::mutex attr_mu;
@@ -926,22 +959,26 @@ int dss_launch_sample_network_pair(const DssModelDev &m, DssBatchDev &b, int n_u
         std::lock_guard<std::mutex> attr_lk(attr_mu);
         if (!(attr_set >> (dev & 63) & 1)) {
 #define DSS_SET_ATTR(K) DSS_HIP_CHECK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, DSS_PAIR_HBLK_BYTES))
-            DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, false, 10>)); DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, false, 12>));
-            DSS_SET_ATTR((lpcnet_sample_pair_kernel<true, false, 10>));  DSS_SET_ATTR((lpcnet_sample_pair_kernel<true, false, 12>));
-            DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, true, 10>));  DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, true, 12>));
+            DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, false, 10, false>)); DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, false, 12, false>));
+            DSS_SET_ATTR((lpcnet_sample_pair_kernel<true, false, 10, false>));  DSS_SET_ATTR((lpcnet_sample_pair_kernel<true, false, 12, false>));
+            DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, true, 10, false>));  DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, true, 12, false>));
+            DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, false, 10, true>));  DSS_SET_ATTR((lpcnet_sample_pair_kernel<false, false, 12, true>));
+            DSS_SET_ATTR((lpcnet_sample_pair_kernel<true, false, 10, true>));   DSS_SET_ATTR((lpcnet_sample_pair_kernel<true, false, 12, true>));
 #undef DSS_SET_ATTR
             attr_set |= 1ull << (dev & 63);
         }
     }
     const dim3 grid((n_utts + 1) / 2), block(512);
-#define DSS_LAUNCH(T, S2)                                                                                              \
+#define DSS_LAUNCH(T, S2, R)                                                                                           \
     do {                                                                                                               \
-        if (z10) hipLaunchKernelGGL((lpcnet_sample_pair_kernel<T, S2, 10>), grid, block, dyn, s, m, b, n_utts, n_frames, d_pcm); \
-        else hipLaunchKernelGGL((lpcnet_sample_pair_kernel<T, S2, 12>), grid, block, dyn, s, m, b, n_utts, n_frames, d_pcm);     \
+        if (z10) hipLaunchKernelGGL((lpcnet_sample_pair_kernel<T, S2, 10, R>), grid, block, dyn, s, m, b, n_utts, n_frames, d_pcm); \
+        else hipLaunchKernelGGL((lpcnet_sample_pair_kernel<T, S2, 12, R>), grid, block, dyn, s, m, b, n_utts, n_frames, d_pcm);     \
     } while (0)
-    if (trace == 2) DSS_LAUNCH(false, true);
-    else if (trace) DSS_LAUNCH(true, false);
-    else DSS_LAUNCH(false, false);
+    if (trace == 2) DSS_LAUNCH(false, true, false);
+    else if (trace && ragged) DSS_LAUNCH(true, false, true);
+    else if (trace) DSS_LAUNCH(true, false, false);
+    else if (ragged) DSS_LAUNCH(false, false, true);
+    else DSS_LAUNCH(false, false, false);
 #undef DSS_LAUNCH
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;

@@ -131,19 +131,21 @@ int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float *d_features
  * sequential) and uploaded on the stream.  This is the shape of the reference's real callers: .npy files
  * of different lengths with a fresh decoder each (local/training.py:182-198), and speech segments of
  * different lengths finishing on some of the 128 streams whose vocoder state carries across segments
- * (local/units.py:524,531-538).  Workgroups are dispatched in row order: put long rows first when
- * n_utts exceeds the 256 CUs.  Calls on one batch object must be issued on one stream at a time. */
+ * (local/units.py:524,531-538).  With counts, workgroups take the rows by decreasing frame count whatever order the
+ * caller used (the library sorts a dispatch list; results do not depend on it), so that short rows fill in behind the
+ * long ones when n_utts exceeds the number of CUs.  Calls on one batch object must be issued on one stream at a time. */
 int dss_lpcnet_batch_synthesize_ragged_dev(dss_lpcnet_batch *b, const float *d_features, const int *slots,
                                            const int *counts, int n_utts, int n_frames, int feat_stride,
                                            short *d_pcm, void *hip_stream);
 int dss_lpcnet_batch_synthesize_ragged(dss_lpcnet_batch *b, const float *features, const int *slots,
                                        const int *counts, int n_utts, int n_frames, int feat_stride, short *pcm);
-/* Kernel choice for uniform calls (no slots / counts).  0 (default): one utterance per workgroup (csrc/lpcnet_sample.hip)
- * while the call has at most one utterance per CU, two utterances per workgroup -- carried as the two halves of packed
- * fp32 instructions, csrc/lpcnet_sample_pair.hip -- beyond; 1 or -1: always one per workgroup; 2: always two (fails with
- * DSS_EINVAL for a model whose CU-resident layout leaves no room for the second utterance).  Ragged calls and models on
- * the extended / generic paths always run one utterance per workgroup.  Results are bit-identical either way, and a
- * decoder state written by one form is continued by the other. */
+/* Kernel choice (uniform and ragged calls).  0 (default): one utterance per workgroup (csrc/lpcnet_sample.hip) while the
+ * call has at most one row per CU, two utterances per workgroup -- carried as the two halves of packed fp32 instructions,
+ * csrc/lpcnet_sample_pair.hip -- beyond; 1 or -1: always one per workgroup; 2: always two (fails with DSS_EINVAL for a
+ * model whose CU-resident layout leaves no room for the second utterance).  In a ragged call the two rows of a workgroup
+ * are neighbours in the dispatch list (near-equal length); they run packed over the frames both have and the longer one
+ * finishes alone.  Models on the extended / generic paths always run one utterance per workgroup.  Results are
+ * bit-identical either way, and a decoder state written by one form is continued by the other. */
 int dss_lpcnet_batch_set_multi(dss_lpcnet_batch *b, int utterances_per_workgroup);
 /* Test taps (device -> host): frame-rate network outputs of the LAST call, per utterance and frame:
  * which = 0: gru_a_condition [n_frames][3*gru_a]; 1: gru_b_condition [n_frames][3*gru_b]; 2: lpc [n_frames][16].

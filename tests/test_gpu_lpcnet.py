@@ -202,6 +202,43 @@ def test_ragged_rows_and_slot_indexed_state(oracle, model):
                 assert pcm.shape == (n * 160,) and np.array_equal(pcm, want), (force_generic, s, a, n)
 
 
+def test_ragged_rows_on_the_pair_kernel(oracle, model):
+    """Ragged calls on the two-utterances-per-workgroup kernel (RAGGED instantiation of lpcnet_sample_pair_kernel; chosen
+    automatically beyond one row per CU, forced here): rows 2k and 2k+1 share a workgroup, run packed over the frames both
+    have, and the longer one finishes alone from the state the packed part left in global memory.  Same call shapes as
+    the reference's bulk callers (local/training.py:182-198, local/units.py:524,531-538).  Rows in the caller's order
+    (no sorting), so that the pairs are the ones written here: longer first, longer second, equal, a zero-frame partner,
+    a lone last row; later calls continue slots with frame_count > 0 next to fresh ones (different numbers of silent
+    frames: such a pair runs one row after the other).  One oracle decoder per slot is the reference."""
+    from dss_amd.lpcnet import LPCNetBatch
+    calls = [                                         # (slot, first frame, number of frames) per row
+        [(3, 0, 6), (0, 0, 2), (4, 0, 1), (1, 0, 5), (2, 0, 3), (5, 0, 3), (6, 0, 0), (7, 0, 4), (8, 0, 2)],
+        [(0, 2, 4), (9, 0, 4), (3, 6, 2), (1, 5, 6), (6, 0, 3), (4, 1, 0), (2, 3, 1)],
+        [(9, 4, 7), (8, 2, 7), (7, 4, 1)],
+    ]
+    feats = {s: synthetic_features(950 + s, 12) for s in range(10)}
+    for trace in (False, True):
+        gpu = LPCNetBatch(10, 7)
+        gpu.set_multi(2)
+        if trace:
+            gpu.enable_trace(True)
+        decs = {s: oracle.decoder(model) for s in range(10)}
+        for rows in calls:
+            got = gpu.synthesize_ragged([feats[s][a:a + n] for s, a, n in rows], slots=[s for s, _, _ in rows], longest_first=False)
+            for (s, a, n), pcm in zip(rows, got):
+                want = [decs[s].synthesize(feats[s][t]) for t in range(a, a + n)]
+                want = np.concatenate(want) if want else np.empty(0, np.int16)
+                assert pcm.shape == (n * 160,) and np.array_equal(pcm, want), (trace, s, a, n)
+    # the offline shape at a size where the rule picks the pair kernel by itself: 600 files, longest first
+    n = 600
+    lengths = [12 if i % 7 == 0 else 2 + (i % 9) for i in range(n)]
+    f2 = synthetic_features(2, 12)
+    want = oracle.lpcnet_utterance(model, f2)
+    got = LPCNetBatch(n, 12).synthesize_ragged([f2[:k] for k in lengths])
+    for k, pcm in zip(lengths, got):
+        assert np.array_equal(pcm, want[:k * 160])
+
+
 def test_ragged_files_fresh_state_longest_first(golden, model):
     """Offline shape: more files than CUs, different lengths, fresh decoder each; rows are dispatched longest first
     and returned in the caller's order."""

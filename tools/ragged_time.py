@@ -28,7 +28,9 @@ feats = torch.from_numpy(np.stack([base] * n)).cuda()
 order = np.argsort(-counts, kind="stable")
 dec = lpcnet.LPCNetBatch(n, fmax)
 out = torch.empty((n, fmax * 160), dtype=torch.int16, device="cuda")
-for name, c in (("ragged, longest first", counts[order]), ("ragged, arrival order", counts), ("padded to the longest", None)):
+for name, c, mode in (("ragged, longest first", counts[order], 0), ("ragged, longest first, one utterance per workgroup", counts[order], 1),
+                      ("ragged, arrival order", counts, 0), ("padded to the longest", None, 0)):
+    dec.set_multi(mode)                        # 0: the library's rule (two utterances per workgroup beyond one row per CU)
     for it in range(2):
         dec.reset()
         torch.cuda.synchronize()
@@ -40,7 +42,7 @@ for name, c in (("ragged, longest first", counts[order]), ("ragged, arrival orde
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
     audio = counts.sum() * 0.01
-    print(f"{name:24s}: {dt * 1e3:8.1f} ms for {audio:.0f} s of audio in {n} utterances -> {audio / dt:7.0f} x RT", flush=True)
+    print(f"{name:52s}: {dt * 1e3:8.1f} ms for {audio:.0f} s of audio in {n} utterances -> {audio / dt:7.0f} x RT", flush=True)
 del dec, feats, out
 
 S = 128
