@@ -242,6 +242,32 @@ def main():
                    "kernel_ms": k4, "kernel_ms_source": "HIP events on the launch stream"}
         del d4, f4, o4
 
+    # The bulk callers' real shape (local/training.py:182-198): files of different lengths, one ragged call, rows in arrival order
+    ragged = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        Br = 1024
+        counts = np.random.default_rng(0).integers(50, 301, Br)              # 0.5 .. 3 s
+        fmax = int(counts.max())
+        fr = torch.from_numpy(np.stack([synthetic_features(0, fmax)] * Br)).cuda()
+        orr = torch.empty((Br, fmax * FRAME), dtype=torch.int16, device="cuda")
+        dr = lpcnet.LPCNetBatch(Br, fmax, device=local_rank)
+
+        def stepr():
+            dr.reset_async()
+            dr.synthesize_ragged_torch(fr, counts, out=orr)
+        stepr(); torch.cuda.synchronize()
+        tr = time.perf_counter()
+        for _ in range(2):
+            stepr()
+        torch.cuda.synchronize()
+        tr = (time.perf_counter() - tr) / 2
+        audio = float(counts.sum()) * FRAME / 16000.0
+        ragged = {"workload": "1024 synthetic utterances of 0.5-3 s (uniform), fresh decoders, one ragged call, rows in arrival order "
+                              "(the library dispatches them by decreasing length; two rows per workgroup beyond one row per CU)",
+                  "ms_per_step": tr * 1e3, "audio_seconds": audio, "value": audio * 16000.0 / tr, "unit": "samples/s",
+                  "x_realtime": audio / tr}
+        del dr, fr, orr
+
     # BASELINE.json configs[2]: 64 segments of 64-channel ECoG (1.04 s) -> HGA -> z-score -> BiLSTM -> LPCNet -> PCM
     config3 = None
     if rank == 0 and world == 1 and not args.no_latency:
@@ -345,6 +371,7 @@ def main():
             "roofline_hbm_equiv": hbm,
             "generic_kernel": generic,
             "config4_per_gpu": config4,
+            "ragged_1024": ragged,
             "config3": config3,
             "cpu_baseline": cpu,
             "latency": latency,
