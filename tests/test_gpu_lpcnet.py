@@ -545,6 +545,13 @@ def test_pair_kernel_bit_exact(oracle, model):
         pcm = gpu.synthesize(feats)
         for b in range(B):
             assert np.array_equal(pcm[b], oracle.lpcnet_utterance(model, feats[b])), (B, F, b)
+    # a long call: 3 utterances x 2 s (32 000 sample steps, 7 hand-overs of the GRU B relay in each)
+    feats = np.stack([synthetic_features(1250 + b, 200) for b in range(3)])
+    gpu = LPCNetBatch(3, 200)
+    gpu.set_multi(2)
+    pcm = gpu.synthesize(feats)
+    for b in range(3):
+        assert np.array_equal(pcm[b], oracle.lpcnet_utterance(model, feats[b])), b
     # chunked: 1, 1, 1, 2, 5 frames through one batch object vs one oracle decoder per utterance
     B, F = 5, 10
     feats = np.stack([synthetic_features(1300 + b, F) for b in range(B)])
