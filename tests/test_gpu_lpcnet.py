@@ -638,7 +638,14 @@ def test_pair_kernel_other_models_and_selection(oracle):
             lpcnet.load_model(blob)
             gpu = LPCNetBatch(9, 5)
             gpu.set_multi(2)
-            assert np.array_equal(gpu.synthesize(feats), _oracle_pcm(oracle, blob, feats))
+            want = _oracle_pcm(oracle, blob, feats)
+            assert np.array_equal(gpu.synthesize(feats), want)
+            # the same rows as a ragged call (RAGGED instantiation of this model's kernel): fresh decoders, lengths 5 .. 1
+            gpu.reset()
+            lens = [5, 2, 4, 4, 1, 3, 5, 0, 2]
+            got = gpu.synthesize_ragged([feats[b, :n] for b, n in enumerate(lens)], longest_first=False)
+            for b, n in enumerate(lens):
+                assert np.array_equal(got[b], want[b, :n * 160]), (b, n)
         lpcnet.load_model(synthetic_blob(0, skew=0.1))
         gpu = LPCNetBatch(9, 5)
         with pytest.raises(_lib.DssError, match="do not fit"):
