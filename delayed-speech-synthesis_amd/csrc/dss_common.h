@@ -125,6 +125,7 @@ struct DssBatchDev {
     const int *slot_of;   // [n] decoder slot continued by row i of the call
     const int *count_of;  // [n] frames of row i (<= n_frames of the call; 0 leaves the slot untouched)
     const int *row_of;    // [n] ragged calls with counts: row handled by the k-th workgroup (slot), longest rows first
+    int utt0;             // first row of this launch of the one-utterance sample kernel (a call split over two launches)
     // trace (optional)
     float *trace_exc, *trace_pcm;   // [B][F*160]
     // teacher forcing (tests; honoured by the TRACE instantiations only): sample k of row u takes the excitation

@@ -369,7 +369,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     static_assert(sizeof(SampleLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
     constexpr bool RG = RAGGED || TRACE;
     // row of this call (scratch, features, PCM): ragged calls with counts start their longest rows first (b.row_of)
-    const int utt = (RG && b.row_of) ? __builtin_amdgcn_readfirstlane(b.row_of[blockIdx.x]) : (int)blockIdx.x;
+    const int utt = (RG && b.row_of) ? __builtin_amdgcn_readfirstlane(b.row_of[blockIdx.x]) : b.utt0 + (int)blockIdx.x;
     const int slot = (RG && b.slot_of) ? b.slot_of[utt] : utt;                     // decoder state it continues
     const int nf = (RG && b.count_of) ? min(b.count_of[utt], n_frames) : n_frames; // its own frame count
     const int tid = threadIdx.x;
@@ -636,9 +636,24 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
     // Calls with more rows than the chip has CUs run two utterances per workgroup (lpcnet_sample_pair.hip: the same
     // roles with the utterances as the halves of packed fp32 instructions); with a CU per utterance the one-utterance
     // form below is faster.  pair: 0 = this rule, -1 = never, 2 = always (tests, A/B timing).
+    b.utt0 = 0;
+    int n_pair = 0;                              // rows [0, n_pair) on the pair kernel, the rest on the kernel below
     if (pair >= 0 && trace <= 2 && !(trace == 2 && (b.slot_of || b.count_of)) && dss_pair_fits(m) &&
-        (pair == 2 || (!trace && n_utts > 128 && n_utts > dss_cu_count())))
-        return dss_launch_sample_network_pair(m, b, n_utts, n_frames, d_pcm, trace, s);
+        (pair == 2 || (!trace && n_utts > 128 && n_utts > dss_cu_count()))) {
+        n_pair = n_utts;
+        // Uniform calls: workgroups run in rounds of one per CU, a round of the pair kernel takes 1.67x a round of the
+        // one-utterance kernel and carries twice the rows.  Full rounds go to the pair kernel; a remainder of at most one
+        // row per CU is cheaper as one round of the one-utterance kernel (600 rows on 256 CUs: 71 + 43 ms instead of 2 x 71).
+        if (pair == 0 && !b.slot_of && !b.count_of) {
+            const int per_round = 2 * dss_cu_count();
+            const int rem = n_utts % per_round;
+            if (rem > 0 && 2 * rem <= per_round && n_utts > per_round) n_pair = n_utts - rem;
+        }
+        const int rc = dss_launch_sample_network_pair(m, b, n_pair, n_frames, d_pcm, trace, s);
+        if (rc || n_pair == n_utts) return rc;
+        b.utt0 = n_pair;
+    }
+    const int n_rows = n_utts - n_pair;          // rows of this launch
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
     // two register-slot capacities are compiled: 10 per gate (no spills) and 12 (a few spilled registers)
     const bool z10 = m.zr_cap <= 10;
@@ -666,10 +681,10 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
     if (m.ext && trace == 2) { dss_set_error("phase stamps are not built for models with z/r tails"); return DSS_EINVAL; }
 #define DSS_LAUNCH(T, S2, R)                                                                                           \
     do {                                                                                                               \
-        if (z10) hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 10, R, false>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm); \
-        else hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 12, R, false>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm);     \
+        if (z10) hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 10, R, false>), dim3(n_rows), dim3(512), dyn, s, m, b, n_frames, d_pcm); \
+        else hipLaunchKernelGGL((lpcnet_sample_kernel<T, S2, 12, R, false>), dim3(n_rows), dim3(512), dyn, s, m, b, n_frames, d_pcm);     \
     } while (0)
-#define DSS_LAUNCH_EXT(T, R) hipLaunchKernelGGL((lpcnet_sample_kernel<T, false, 10, R, true>), dim3(n_utts), dim3(512), dyn, s, m, b, n_frames, d_pcm)
+#define DSS_LAUNCH_EXT(T, R) hipLaunchKernelGGL((lpcnet_sample_kernel<T, false, 10, R, true>), dim3(n_rows), dim3(512), dyn, s, m, b, n_frames, d_pcm)
     if (m.ext) {
         if (trace) DSS_LAUNCH_EXT(true, false);
         else if (ragged) DSS_LAUNCH_EXT(false, true);
@@ -681,6 +696,7 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
     else DSS_LAUNCH(false, false, false);
 #undef DSS_LAUNCH
 #undef DSS_LAUNCH_EXT
+    b.utt0 = 0;
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }

@@ -141,7 +141,9 @@ int dss_lpcnet_batch_synthesize_ragged(dss_lpcnet_batch *b, const float *feature
                                        const int *counts, int n_utts, int n_frames, int feat_stride, short *pcm);
 /* Kernel choice (uniform and ragged calls).  0 (default): one utterance per workgroup (csrc/lpcnet_sample.hip) while the
  * call has at most one row per CU, two utterances per workgroup -- carried as the two halves of packed fp32 instructions,
- * csrc/lpcnet_sample_pair.hip -- beyond; 1 or -1: always one per workgroup; 2: always two (fails with DSS_EINVAL for a
+ * csrc/lpcnet_sample_pair.hip -- beyond (a uniform call is split: full rounds of two rows per CU on the pair kernel, a
+ * remainder of at most one row per CU as one round of the one-utterance kernel); 1 or -1: always one per workgroup; 2:
+ * always two (fails with DSS_EINVAL for a
  * model whose CU-resident layout leaves no room for the second utterance).  In a ragged call the two rows of a workgroup
  * are neighbours in the dispatch list (near-equal length); they run packed over the frames both have and the longer one
  * finishes alone.  Models on the extended / generic paths always run one utterance per workgroup.  Results are
