@@ -655,8 +655,9 @@ def test_pair_kernel_other_models_and_selection(oracle):
 
 
 def test_pair_kernel_is_chosen_beyond_one_utterance_per_cu(golden, model):
-    """600 utterances on 256 CUs: the automatic choice (pair kernel) and the forced latency kernel agree bit for bit with
-    each other and with the golden utterance; an odd count exercises the half-filled last workgroup at full scale."""
+    """601 utterances on 256 CUs: the automatic choice (one full round of 512 rows on the pair kernel, the remaining 89 as
+    one round of the one-utterance kernel, which starts at row 512: b.utt0), the forced pair kernel (an odd count: its last
+    workgroup is half filled) and the forced latency kernel agree bit for bit with each other and with the golden utterance."""
     from dss_amd.lpcnet import LPCNetBatch
     g = golden("lpcnet_self.npz")
     B, F = 601, 30
@@ -671,6 +672,11 @@ def test_pair_kernel_is_chosen_beyond_one_utterance_per_cu(golden, model):
     gpu.enable_timing(True)
     one = gpu.synthesize(feats)
     t_one = gpu.kernel_ms(0)
-    assert np.array_equal(auto, one)
+    gpu.reset()
+    gpu.set_multi(2)
+    gpu.enable_timing(True)
+    two = gpu.synthesize(feats)
+    t_two = gpu.kernel_ms(0)
+    assert np.array_equal(auto, one) and np.array_equal(auto, two)
     assert np.array_equal(auto[0], g["utt2_pcm"]) and np.array_equal(auto[600], g["utt2_pcm"])
-    print(f"601 x {F} frames: auto {t_auto:.1f} ms, one utterance per workgroup {t_one:.1f} ms")
+    print(f"601 x {F} frames: auto {t_auto:.1f} ms, one utterance per workgroup {t_one:.1f} ms, two {t_two:.1f} ms")
