@@ -291,6 +291,14 @@ struct FastLayout {
     std::vector<int> unit_of, unit_h, wave_nh, grp_hoff, wave_nzr, wave_nzt;
     std::vector<float> zr_w, hblk;
     std::vector<unsigned> zr_col, h_col;
+    // packed-rows h image (lpcnet_sample_pkh.hip)
+    int pk_ok = 0, pk_floats = 0;
+    std::vector<int> pk_hoff, pk_unit, pk_nh;
+    std::vector<float> hblk_pk;
+    std::vector<unsigned> pk_hcol;
+    std::vector<int> pk_unit_of, pk_wave_nzr;
+    std::vector<float> pk_zr_w;
+    std::vector<unsigned> pk_zr_col;
 };
 
 static void build_fast_layout(const BlobView &v, int NA, FastLayout &F)
@@ -450,6 +458,88 @@ static void build_fast_layout(const BlobView &v, int NA, FastLayout &F)
             }
     }
     F.fast_ok = fast_ok; F.zmax = zmax; F.hmax = hmax; F.zr_cap = zr_cap; F.ext = fast_ok ? ext : 0; F.ext_tab = ext_tab; F.hfloats = hfloats;
+
+    // ---- packed-rows h image of lpcnet_sample_pkh.hip --------------------------------------------------------------
+    // Three waves x 16 row groups; a lane carries rows q and q + 4 (q = lane & 3) of its group's blocks as the halves of
+    // packed fp32 instructions.  Record of a block: [half 2][q 4][4 floats] = (W[q][c], W[q+4][c], W[q][c+1], W[q+4][c+1]),
+    // c = 2 * half, so a lane's two ds_read_b128 of a block are 64 bytes apart and the four lanes of a group read 64
+    // consecutive bytes each time.  Lists back to back per wave (same over-read convention as above: surplus slots read on
+    // into the following records and multiply them by "column 96"); the list of group gi of a wave starts at
+    // 64 * (gi & 3) bytes modulo 256, so that the four groups of a 16-lane pass of a ds_read_b128 cover all 64 banks.
+    // Groups sorted by h block count: the wave of rank 0 gets the 16 longest lists.
+    static const int pk_rank_wave[3] = {0, 1, 2};           // h wave index: 0, 1, 2 = waves 0, 1, 5 of the kernel
+    F.pk_ok = fast_ok && hmax <= DSS_HC;
+    F.pk_hoff.assign(G, 0); F.pk_unit.assign(192, 0); F.pk_nh.assign(4, 0);
+    F.pk_hcol.assign((size_t)(DSS_HC / 4) * 192, 0u);
+    F.pk_floats = 4;
+    if (F.pk_ok) {
+        std::vector<int> pk_grp(G, 0);
+        for (int rk = 0; rk < 3; ++rk) {
+            const int wv = pk_rank_wave[rk];
+            int nh = 0;
+            for (int gi = 0; gi < 16; ++gi) {
+                pk_grp[wv * 16 + gi] = order_h[rk * 16 + gi];
+                nh = std::max(nh, cnt[2 * G + order_h[rk * 16 + gi]]);
+            }
+            F.pk_nh[wv] = (nh + 1) & ~1;
+        }
+        int pf = 0, pend = 0;
+        for (int wv = 0; wv < 3; ++wv)
+            for (int gi = 0; gi < 16; ++gi) {
+                pf += ((16 * (gi & 3) - pf) % 64 + 64) % 64;
+                F.pk_hoff[wv * 16 + gi] = pf;
+                pf += cnt[2 * G + pk_grp[wv * 16 + gi]] * 32;
+                pend = std::max(pend, F.pk_hoff[wv * 16 + gi] + (F.pk_nh[wv] + 2) * 32);     // + 2: the kernel fetches two slots ahead
+            }
+        pf = (std::max(pf, pend) + 3) & ~3;
+        F.pk_floats = pf;
+        F.hblk_pk.assign((size_t)pf, 0.f);
+        for (int tid = 0; tid < 192; ++tid) {
+            const int wv = tid / 64, gi = (tid & 63) >> 2, q = tid & 3;
+            const int grp = pk_grp[wv * 16 + gi], g = 2 * G + grp;
+            F.pk_unit[tid] = grp * 8 + q;
+            for (int sl = 0; sl < cnt[g]; ++sl) {
+                const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                float *rec = F.hblk_pk.data() + F.pk_hoff[wv * 16 + gi] + (size_t)sl * 32;
+                for (int c = 0; c < 4; ++c) {
+                    rec[(c >> 1) * 16 + q * 4 + 2 * (c & 1) + 0] = wb[c * 8 + q];
+                    rec[(c >> 1) * 16 + q * 4 + 2 * (c & 1) + 1] = wb[c * 8 + q + 4];
+                }
+                F.pk_hcol[(size_t)(sl >> 2) * 192 + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
+            }
+            for (int sl = cnt[g]; sl < DSS_HC; ++sl) F.pk_hcol[(size_t)(sl >> 2) * 192 + tid] |= 96u << (8 * (sl & 3));
+        }
+    } else {
+        F.hblk_pk.assign(4, 0.f);
+    }
+    // z/r lane assignment of that kernel: its dual-FC sits on waves 2, 3, 6, 7 and its h chains on waves 0, 1, 5, so the 16 row
+    // groups with the most z/r blocks go to waves 2 and 3 (up to 10 register slots per gate), the rest to waves 4, 5, 1, 0 with
+    // 8 slots -- the lightest beside the longest h chains.  No tails: a model that needs them stays on lpcnet_sample.hip.
+    static const int pk_rank_wave_zr[6] = {2, 3, 4, 5, 1, 0};
+    F.pk_unit_of.assign(NA, 0); F.pk_wave_nzr.assign(8, 0);
+    F.pk_zr_w.assign((size_t)2 * DSS_ZRC * 4 * NA, 0.f);
+    F.pk_zr_col.assign((size_t)(2 * DSS_ZRC / 4) * NA, 0u);
+    for (int rk = 0; rk < 6 && F.pk_ok; ++rk) {
+        const int wv = pk_rank_wave_zr[rk], cap = (wv == 2 || wv == 3) ? 10 : 8;
+        int nzr = 0;
+        for (int q = 0; q < 8; ++q) nzr = std::max(nzr, std::max(cnt[order_zr[rk * 8 + q]], cnt[G + order_zr[rk * 8 + q]]));
+        if (nzr > cap) { F.pk_ok = 0; break; }
+        F.pk_wave_nzr[wv] = (nzr + 1) & ~1;
+        for (int q = 0; q < 8; ++q)
+            for (int r = 0; r < 8; ++r) {
+                const int tid = wv * 64 + q * 8 + r, grp = order_zr[rk * 8 + q];
+                F.pk_unit_of[tid] = grp * 8 + r;
+                for (int gate = 0; gate < 2; ++gate) {
+                    const int g = gate * G + grp;
+                    for (int sl = 0; sl < cnt[g]; ++sl) {
+                        const int s2 = gate * DSS_ZRC + sl;
+                        const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
+                        for (int k = 0; k < 4; ++k) F.pk_zr_w[((size_t)s2 * 4 + k) * NA + tid] = wb[k * 8 + r];
+                        F.pk_zr_col[(size_t)(s2 >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (s2 & 3));
+                    }
+                }
+            }
+    }
 }
 
 static int upload_model(HostModel *hm, int device, DssModelDev &m)
@@ -554,6 +644,27 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         rc = dev_upload<unsigned>(zr_col.data(), zr_col.size(), &du); if (rc) return rc; m.zr_col = du;
         rc = dev_upload<unsigned>(h_col.data(), h_col.size(), &du); if (rc) return rc; m.h_col = du;
         rc = dev_upload<float>(hblk.data(), hblk.size(), &df); if (rc) return rc; m.hblk = df;
+        m.pkh_ok = F.pk_ok; m.hblk_pk_floats = F.pk_floats;
+        rc = dev_upload<float>(F.hblk_pk.data(), F.hblk_pk.size(), &df); if (rc) return rc; m.hblk_pk = df;
+        rc = dev_upload<int>(F.pk_hoff.data(), F.pk_hoff.size(), &di); if (rc) return rc; m.pk_hoff = di;
+        rc = dev_upload<int>(F.pk_unit.data(), F.pk_unit.size(), &di); if (rc) return rc; m.pk_unit = di;
+        rc = dev_upload<int>(F.pk_nh.data(), F.pk_nh.size(), &di); if (rc) return rc; m.pk_nh = di;
+        rc = dev_upload<unsigned>(F.pk_hcol.data(), F.pk_hcol.size(), &du); if (rc) return rc; m.pk_hcol = du;
+        rc = dev_upload<int>(F.pk_unit_of.data(), F.pk_unit_of.size(), &di); if (rc) return rc; m.pk_unit_of = di;
+        rc = dev_upload<int>(F.pk_wave_nzr.data(), F.pk_wave_nzr.size(), &di); if (rc) return rc; m.pk_wave_nzr = di;
+        rc = dev_upload<float>(F.pk_zr_w.data(), F.pk_zr_w.size(), &df); if (rc) return rc; m.pk_zr_w = df;
+        rc = dev_upload<unsigned>(F.pk_zr_col.data(), F.pk_zr_col.size(), &du); if (rc) return rc; m.pk_zr_col = du;
+        if (F.pk_ok) {  // embedding rows in that kernel's lane order
+            const float *tabs[3] = {v.embed_sig, v.embed_pred, v.embed_exc};
+            std::vector<float> perm((size_t)256 * NA * 3);
+            for (int t = 0; t < 3; ++t) {
+                for (int idx = 0; idx < 256; ++idx)
+                    for (int tid = 0; tid < NA; ++tid)
+                        for (int g = 0; g < 3; ++g)
+                            perm[((size_t)idx * NA + tid) * 3 + g] = tabs[t][(size_t)idx * 3 * NA + (size_t)g * NA + F.pk_unit_of[tid]];
+                rc = dev_upload<float>(perm.data(), perm.size(), &df); if (rc) return rc; m.pk_embed_lane[t] = df;
+            }
+        }
         // GRU B input weights for the two relay waves, j-major with lane = row: [384][64]
         std::vector<float> gbl((size_t)NA * 64, 0.f);
         for (int j = 0; j < NA; ++j)
@@ -1066,6 +1177,7 @@ extern "C" void lpcnet_destroy(LPCNetState *st)
 }
 
 // one frame through the captured graph; DSS_OK, or an error after which the caller falls back to the eager path for good
+#define DSS_EINTERNAL_REPLAY (-1000)      // the replay itself failed (the frame was enqueued): see lpcnet_synthesize
 static int level1_graph_frame(LPCNetState *st, const float *features, short *output)
 {
     dss_lpcnet_batch *b = st->b;
@@ -1094,9 +1206,14 @@ static int level1_graph_frame(LPCNetState *st, const float *features, short *out
         hipGraphDestroy(graph);
         if (e4 != hipSuccess) { st->exec = nullptr; dss_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e4)); return DSS_ENODEV; }
     }
-    DSS_HIP_CHECK(hipGraphLaunch(st->exec, st->stream));
-    DSS_HIP_CHECK(hipStreamSynchronize(st->stream));
+    // From here on the frame IS enqueued: a failure must not be answered with an eager re-run (the decoder state may have
+    // advanced already), so it gets its own code: the caller zero-fills this frame and stays eager afterwards.
+    if (hipGraphLaunch(st->exec, st->stream) != hipSuccess || hipStreamSynchronize(st->stream) != hipSuccess) {
+        dss_set_error("level-1 graph replay failed: %s", hipGetErrorString(hipGetLastError()));
+        return DSS_EINTERNAL_REPLAY;
+    }
     memcpy(output, st->h_pcm, DSS_FRAME_SIZE * sizeof(short));
+    b->last_utts = 1; b->last_frames = 1;
     return DSS_OK;
 }
 
@@ -1124,8 +1241,12 @@ extern "C" void lpcnet_synthesize(LPCNetState *st, const float *features, short 
     }
     // first call of a state: eager (it also sets the kernels' attributes); traced or timed states stay eager
     if (st->calls++ > 0 && !st->graph_off && !st->b->trace && !st->b->timing) {
-        if (level1_graph_frame(st, features, output) == DSS_OK) return;
-        st->graph_off = 1;               // nothing was enqueued by a failed capture: run this frame eagerly
+        const int grc = level1_graph_frame(st, features, output);
+        if (grc == DSS_OK) return;
+        st->graph_off = 1;               // eager launches from now on
+        // a failed capture or instantiation enqueued nothing: this frame runs eagerly below.  A failed replay may have
+        // advanced the decoder: silence for this one frame, no second pass over the same features.
+        if (grc == DSS_EINTERNAL_REPLAY) { synth_failed(output, N); return; }
     }
     if (dss_lpcnet_batch_synthesize(st->b, features, 1, 1, DSS_NB_FEATURES, output)) synth_failed(output, N);
 }
@@ -1255,8 +1376,58 @@ extern "C" int dss_selftest_fast_layout(const void *blob, size_t len, int *info)
     }
     for (int u = 0; u < NA; ++u) if (seen_zr[u] != 1 || seen_h[u] != 1) ++mismatches;
     if ((size_t)F.hfloats * sizeof(float) > DSS_HBLK_BYTES) ++mismatches;
+    if (F.pk_ok) {      // the packed-rows h image of lpcnet_sample_pkh.hip: rows q and q + 4 of every lane of waves 0..2
+        std::vector<int> seen_pk(NA, 0);
+        for (int tid = 0; tid < 192; ++tid) {
+            const int wave = tid / 64, q = tid & 3, nh = F.pk_nh[wave];
+            if (nh > DSS_HC || (nh & 1)) ++mismatches;
+            for (int half = 0; half < 2; ++half) {
+                const int unit = F.pk_unit[tid] + 4 * half;
+                if (unit < 0 || unit >= NA || (F.pk_unit[tid] & 7) != q) { ++mismatches; continue; }
+                ++seen_pk[unit];
+                std::vector<Blk> got;
+                for (int sl = 0; sl < nh; ++sl) {
+                    const int off = F.pk_hoff[tid >> 2] + sl * 32;
+                    if (off < 0 || off + 32 + 64 > F.pk_floats) { ++oob; continue; }     // + 2 records fetched ahead
+                    Blk b;
+                    b.col = (int)((F.pk_hcol[(size_t)(sl >> 2) * 192 + tid] >> (8 * (sl & 3))) & 0xFF);
+                    // the kernel's two ds_read_b128 of this lane: (off + q*4 .. +3) = columns 0, 1; (off + 16 + q*4 ..) = columns 2, 3
+                    for (int c = 0; c < 4; ++c) b.w[c] = F.hblk_pk[off + (c >> 1) * 16 + q * 4 + 2 * (c & 1) + half];
+                    got.push_back(b);
+                }
+                compare(got, 2 * G + unit / 8, unit & 7);
+            }
+            if (F.pk_hoff[tid >> 2] % 64 != 16 * ((tid >> 2) & 3)) ++mismatches;      // bank placement of the group's list
+        }
+        for (int u = 0; u < NA; ++u) if (seen_pk[u] != 1) ++mismatches;
+        std::vector<int> seen_pz(NA, 0);      // ... and that kernel's z/r lane assignment
+        for (int tid = 0; tid < NA; ++tid) {
+            const int wave = tid / 64, unit = F.pk_unit_of[tid], nzr = F.pk_wave_nzr[wave];
+            if (unit < 0 || unit >= NA || nzr > ((wave == 2 || wave == 3) ? 10 : 8)) { ++mismatches; continue; }
+            ++seen_pz[unit];
+            for (int gate = 0; gate < 2; ++gate) {
+                std::vector<Blk> got;
+                for (int sl = 0; sl < nzr; ++sl) {
+                    const int s2 = gate * DSS_ZRC + sl;
+                    Blk b;
+                    b.col = (F.pk_zr_col[(size_t)(s2 >> 2) * NA + tid] >> (8 * (s2 & 3))) & 0xFF;
+                    for (int k = 0; k < 4; ++k) b.w[k] = F.pk_zr_w[((size_t)s2 * 4 + k) * NA + tid];
+                    got.push_back(b);
+                }
+                compare(got, gate * G + unit / 8, unit & 7);
+            }
+        }
+        for (int u = 0; u < NA; ++u) if (seen_pz[u] != 1) ++mismatches;
+    }
     info[5] = tails / 8;             // every tail block is seen by the 8 lanes of its row group
     info[6] = mismatches; info[7] = oob;
+    return DSS_OK;
+}
+
+extern "C" int dss_selftest_lpcnet_latency_kernel(int which)
+{
+    if (which < 0 || which > 2) { dss_set_error("latency kernel: 0 (choose), 1 (lpcnet_sample.hip), 2 (lpcnet_sample_pkh.hip)"); return DSS_EINVAL; }
+    g_dss_latency_kernel = which;
     return DSS_OK;
 }
 
@@ -1330,7 +1501,8 @@ struct dss_hga {
     double *d_in = nullptr, *d_out = nullptr;
     size_t in_cap = 0, out_cap = 0;
     double *d_zs[2] = {nullptr, nullptr};                  // z-score mean / std on the device ...
-    std::vector<double> zs_host[2];                        // ... and on the host (host-buffer entry points)
+    std::vector<double> zs_host[2];                        // ... and on the host (host-buffer entry points); empty = no z-score
+    std::vector<double> zs_dev[2];                         // the values the resident device copies hold (dss_hga_set_zscore)
 };
 
 static int hga_grow_rows(dss_hga *h, int need_rows)
@@ -1448,21 +1620,32 @@ extern "C" int dss_hga_set_zscore(dss_hga *h, const double *means, const double 
 {
     if (!h || (!means) != (!stds)) { dss_set_error("z-score needs both means and stds (or neither)"); return DSS_EINVAL; }
     DSS_HIP_CHECK(hipSetDevice(h->device));
-    for (int k = 0; k < 2; ++k) { if (h->d_zs[k]) hipFree(h->d_zs[k]); h->d_zs[k] = nullptr; h->zs_host[k].clear(); }
+    // The device copies stay resident: clearing only drops the pointers the kernels see, and setting the values that are
+    // already there only restores them -- a caller that toggles the epilogue per call (SegmentPipeline's intermediates
+    // tap) pays no hipFree / hipMalloc / copy, i.e. no device-wide synchronisation, in its hot path.
     h->d.zs_mean = h->d.zs_std = nullptr;
+    h->zs_host[0].clear(); h->zs_host[1].clear();
     if (!means) return DSS_OK;
-    if (dev_upload<double>(means, h->d.C, &h->d_zs[0]) || dev_upload<double>(stds, h->d.C, &h->d_zs[1])) return DSS_ENOMEM;
-    h->zs_host[0].assign(means, means + h->d.C);
-    h->zs_host[1].assign(stds, stds + h->d.C);
+    const size_t C = (size_t)h->d.C;
+    const bool same = h->d_zs[0] && h->d_zs[1] && h->zs_dev[0].size() == C && !memcmp(h->zs_dev[0].data(), means, C * sizeof(double)) &&
+                      !memcmp(h->zs_dev[1].data(), stds, C * sizeof(double));
+    if (!same) {
+        for (int k = 0; k < 2; ++k) { if (h->d_zs[k]) hipFree(h->d_zs[k]); h->d_zs[k] = nullptr; h->zs_dev[k].clear(); }
+        if (dev_upload<double>(means, C, &h->d_zs[0]) || dev_upload<double>(stds, C, &h->d_zs[1])) return DSS_ENOMEM;
+        h->zs_dev[0].assign(means, means + C);
+        h->zs_dev[1].assign(stds, stds + C);
+    }
+    h->zs_host[0] = h->zs_dev[0];
+    h->zs_host[1] = h->zs_dev[1];
     h->d.zs_mean = h->d_zs[0]; h->d.zs_std = h->d_zs[1];
     return DSS_OK;
 }
 
 /* Tests and A/B timing only: 0 = choose (default: hga_fused_kernel, three launches when its ring does not fit),
- * 1 = hga_fused_kernel, 2 = the three-launch form, 3 = hga_stream_kernel (one launch also for raw packets). */
+ * 1 = hga_fused_kernel, 2 = the three-launch form. */
 extern "C" int dss_selftest_hga_force_path(dss_hga *h, int path)
 {
-    if (!h || path < 0 || path > 3) return DSS_EINVAL;
+    if (!h || path < 0 || path > 2) return DSS_EINVAL;
     h->d.force_path = path;
     return DSS_OK;
 }
@@ -1537,9 +1720,7 @@ extern "C" int dss_hga_extract_raw_dev(dss_hga *h, const double *d_raw, int n, d
     if (!h || !h->c_raw) { dss_set_error("no front end configured (dss_hga_set_frontend)"); return DSS_EINVAL; }
     if (!d_raw || !d_out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
     DSS_HIP_CHECK(hipSetDevice(h->device));
-    // one launch from the raw packet to the frames: the streamed form, on request (it measured slower than two launches)
-    const DssHgaFrontDev fe = {d_raw, h->c_raw, h->n_grids, h->d_src_col, h->d_grid_of, h->d_comp_cols, h->d_comp_off};
-    if (dss_hga_stream_fits(h->d, &fe)) return hga_run(h, nullptr, &fe, n, d_out, apply_log, (hipStream_t)hip_stream);
+    // two launches: the front end (HBM-bound), then the extractor (a one-launch form measured slower, profiles/r3_hga_experiment.md)
     const size_t need = (size_t)h->d.S * n * h->d.C;
     if (need > h->pre_cap) {
         if (h->d_pre) hipFree(h->d_pre);

@@ -96,6 +96,20 @@ struct DssModelDev {
     const float *gb_w_lane;       // [384][64] GRU B input weights, input-major, lane = row (rows 48..63 zero)
     const float *fc_w_pair;       // dual-FC weights as [k 8][node 256][4]: (layer 0, layer 1) weights of inputs 2k, 2k+1 (pair kernel)
     const float *gb_w_quad;       // the same weights as [384/4][64 lanes][4 inputs]: one 16-byte load per lane and block of four inputs
+    // packed-rows h-gate layout of lpcnet_sample_pkh.hip: three waves, lane = rows q and q + 4 (q = lane & 3) of row group lane >> 2
+    int pkh_ok;                   // 1 when every h list fits the register-held column ids (DSS_HC)
+    int hblk_pk_floats;           // size of hblk_pk
+    const float *hblk_pk;         // LDS image: per block [half 2][q 4][(W[q][c], W[q+4][c], W[q][c+1], W[q+4][c+1])], c = 2 * half
+    const int *pk_hoff;           // [48]  per (h wave 0..2, lane / 4): float offset of that row group's records inside hblk_pk
+    const int *pk_unit;           // [192] lane of h waves 0..2 (= waves 0, 1, 5) -> GRU A unit of its first row (the second is + 4)
+    const int *pk_nh;             // [4]   per h wave 0..2: h-gate slots (even)
+    const unsigned *pk_hcol;      // [DSS_HC/4][192] four 8-bit block column ids per word
+    // ... and its own z/r lane assignment (the 16 row groups with the most z/r blocks on waves 2 and 3): same formats as
+    // unit_of / wave_nzr / zr_w / zr_col / embed_lane above
+    const int *pk_unit_of, *pk_wave_nzr;
+    const float *pk_zr_w;
+    const unsigned *pk_zr_col;
+    const float *pk_embed_lane[3];
 };
 
 // ---- per-batch device state ---------------------------------------------------------------------------
@@ -145,6 +159,11 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
 int dss_launch_sample_network_pair(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm, int trace,
                                    hipStream_t s);
 int dss_pair_fits(const DssModelDev &m);
+int dss_launch_sample_network_pkh(const DssModelDev &m, DssBatchDev &b, int n_rows, int n_frames, short *d_pcm, int trace,
+                                  hipStream_t s);
+int dss_pkh_fits(const DssModelDev &m);
+// tests / A-B timing only: 0 = choose (the packed-h form when the model fits it), 1 = lpcnet_sample.hip, 2 = lpcnet_sample_pkh.hip
+extern int g_dss_latency_kernel;
 int dss_launch_sample_network_generic(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
                                       int trace, hipStream_t s);
 int dss_launch_exp10_selftest(const float *d_x, const float *d_comp, float *d_out, long n, hipStream_t s);
@@ -176,7 +195,7 @@ struct DssHgaDev {
     double *rows;      // [S][cap_rows][C]
     double sos[2][8][6];
     const double *zs_mean, *zs_std;   // optional z-score of the frames, [C] each (device-resident entry points)
-    int force_path;    // tests / A-B timing only: 0 choose, 1 hga_fused_kernel, 2 the three-launch form, 3 hga_stream_kernel
+    int force_path;    // tests / A-B timing only: 0 choose, 1 hga_fused_kernel, 2 the three-launch form
 };
 // the front end of a call (local/common.py:16-58,308-345): raw amplifier rows (S, n, c_raw) instead of (S, n, C)
 struct DssHgaFrontDev {
@@ -184,9 +203,7 @@ struct DssHgaFrontDev {
     int c_raw, n_grids;
     const int *src_col, *grid_of, *comp_cols, *comp_off;
 };
-// fe == nullptr: d_data is (S, n, C).  With fe: returns DSS_EINVAL when the one-launch form cannot take this shape
-// (C not a multiple of 16, or the tiles do not fit LDS); the caller then runs dss_launch_hga_frontend first.
-int dss_hga_stream_fits(const DssHgaDev &h, const DssHgaFrontDev *fe);
+// d_data is (S, n, C); fe must be nullptr (raw amplifier rows go through dss_launch_hga_frontend first)
 int dss_launch_hga(const DssHgaDev &h, const double *d_data, const DssHgaFrontDev *fe, int n, int row0, int zero_rows, int rows,
                    int W, double *d_out, int apply_log, hipStream_t s);
 int dss_launch_hga_frontend(const double *d_raw, double *d_pre, int S, int n, int c_raw, int C, const int *src_col,

@@ -616,6 +616,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     }
 }
 
+int g_dss_latency_kernel = 0;
+
 // Number of CUs of the current device, asked once per device (the eager streaming tick launches this kernel every 40 ms).
 static int dss_cu_count()
 {
@@ -654,6 +656,14 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
         b.utt0 = n_pair;
     }
     const int n_rows = n_utts - n_pair;          // rows of this launch
+    // One utterance per workgroup: the packed-h form (lpcnet_sample_pkh.hip) for every model it fits; the kernel below for
+    // models with extended paths or 12 z/r register slots (g_dss_latency_kernel: tests and A/B timing)
+    if (g_dss_latency_kernel != 1 && dss_pkh_fits(m)) {
+        const int rc = dss_launch_sample_network_pkh(m, b, n_rows, n_frames, d_pcm, trace, s);
+        b.utt0 = 0;
+        return rc;
+    }
+    if (g_dss_latency_kernel == 2) { b.utt0 = 0; dss_set_error("the packed-h kernel does not fit this model"); return DSS_EINVAL; }
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
     // two register-slot capacities are compiled: 10 per gate (no spills) and 12 (a few spilled registers)
     const bool z10 = m.zr_cap <= 10;

@@ -61,52 +61,6 @@ struct PairLds {
 static_assert(sizeof(PairLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
 static_assert(sizeof(PairLds) + DSS_PAIR_HBLK_BYTES <= 160 * 1024, "LDS budget");
 
-// ---- packed fp32 with a broadcast weight --------------------------------------------------------------------------
-// (w.x * x.x, w.x * x.y) and (w.y * x.x, w.y * x.y): src0 low half (high half) to both lanes of the packed multiply
-__device__ __forceinline__ f32x2 dss_pk_mul_lo(f32x2 w, f32x2 x)
-{
-    f32x2 r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(x));
-    return r;
-}
-__device__ __forceinline__ f32x2 dss_pk_mul_hi(f32x2 w, f32x2 x)
-{
-    f32x2 r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "v"(x));
-    return r;
-}
-// One 8x4 block (or four consecutive dense inputs) of ONE dependent chain, software-pipelined: the four sums of this
-// block's products P (formed one step earlier) alternate with the four products Q of the NEXT block, so that every
-// dependent v_pk_add_f32 (8.9 cycles of latency) has an independent multiplication behind it.  W = (w0, w1) (w2, w3);
-// X0..X3 = the (A, B) pairs of the next block's inputs 0..3.  Products go to registers of their own (the inputs are
-// halves of 128-bit LDS reads: modified in place, half of them were copied first).
-#define DSS_PK_STEP4(ACC, P, Q, X, WLO, WHI)                                                     \
-    asm("v_pk_add_f32 %[a], %[a], %[p0]\n\t"                                                     \
-        "v_pk_mul_f32 %[q0], %[wl], %[x0] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_add_f32 %[a], %[a], %[p1]\n\t"                                                     \
-        "v_pk_mul_f32 %[q1], %[wl], %[x1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
-        "v_pk_add_f32 %[a], %[a], %[p2]\n\t"                                                     \
-        "v_pk_mul_f32 %[q2], %[wh], %[x2] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_add_f32 %[a], %[a], %[p3]\n\t"                                                     \
-        "v_pk_mul_f32 %[q3], %[wh], %[x3] op_sel:[1,0] op_sel_hi:[1,1]"                          \
-        : [a] "+v"(ACC), [q0] "=&v"((Q)[0]), [q1] "=&v"((Q)[1]), [q2] "=&v"((Q)[2]), [q3] "=&v"((Q)[3]) \
-        : [p0] "v"((P)[0]), [p1] "v"((P)[1]), [p2] "v"((P)[2]), [p3] "v"((P)[3]),                \
-          [x0] "v"((X).a.lo), [x1] "v"((X).a.hi), [x2] "v"((X).c.lo), [x3] "v"((X).c.hi), [wl] "v"(WLO), [wh] "v"(WHI))
-// the first block's products (nothing to add yet) and the last block's sums (nothing left to multiply)
-#define DSS_PK_MUL4(Q, X, WLO, WHI)                                                              \
-    asm("v_pk_mul_f32 %[q0], %[wl], %[x0] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_mul_f32 %[q1], %[wl], %[x1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"                      \
-        "v_pk_mul_f32 %[q2], %[wh], %[x2] op_sel_hi:[0,1]\n\t"                                   \
-        "v_pk_mul_f32 %[q3], %[wh], %[x3] op_sel:[1,0] op_sel_hi:[1,1]"                          \
-        : [q0] "=&v"((Q)[0]), [q1] "=&v"((Q)[1]), [q2] "=&v"((Q)[2]), [q3] "=&v"((Q)[3])         \
-        : [x0] "v"((X).a.lo), [x1] "v"((X).a.hi), [x2] "v"((X).c.lo), [x3] "v"((X).c.hi), [wl] "v"(WLO), [wh] "v"(WHI))
-#define DSS_PK_ADD4(ACC, P)                                                                      \
-    asm("v_pk_add_f32 %[a], %[a], %[p0]\n\t"                                                     \
-        "v_pk_add_f32 %[a], %[a], %[p1]\n\t"                                                     \
-        "v_pk_add_f32 %[a], %[a], %[p2]\n\t"                                                     \
-        "v_pk_add_f32 %[a], %[a], %[p3]"                                                         \
-        : [a] "+v"(ACC)                                                                          \
-        : [p0] "v"((P)[0]), [p1] "v"((P)[1]), [p2] "v"((P)[2]), [p3] "v"((P)[3]))
 // One 8x4 block of the z gate and one of the r gate: two independent chains, so the sums of one hide the latency of the
 // other and the products need no pipelining across blocks.  T[0..3] z products, T[4..7] r products (temporaries).
 #define DSS_PK_ZR_MUL(T, XZ, XR, WZLO, WZHI, WRLO, WRHI)                                         \
@@ -225,14 +179,6 @@ __device__ __forceinline__ void dss_sigmoid_pk2(const float *tab, f32x2 x, f32x2
     dss_tanh_pk2(tab, .5f * x, .5f * w, tx, tw);
     ox = .5f + .5f * tx;
     ow = .5f + .5f * tw;
-}
-
-// a pair buffer of one 8x4 block: the block's four inputs for both utterances (two ds_read_b128)
-struct PairX { f32x4 a, c; };          // a = inputs 0, 1; c = inputs 2, 3; each as (A, B)
-__device__ __forceinline__ void dss_pair_loadx(PairX &q, const char *p)
-{
-    q.a = *reinterpret_cast<const f32x4 *>(p);
-    q.c = *reinterpret_cast<const f32x4 *>(p + 16);
 }
 
 // Speculation for one candidate excitation value and both utterances: the output sample, the next LPC prediction (the

@@ -113,8 +113,7 @@ class HgaExtractorGPU:
         _lib.check(self._L.dss_hga_set_zscore(self._h, m.ctypes.data, sd.ctypes.data))
 
     def _force_path(self, path: int):
-        """Tests / A-B timing only: 0 choose, 1 hga_fused_kernel, 2 three launches, 3 hga_stream_kernel (one launch also for raw
-        packets) (dss_selftest_hga_force_path)."""
+        """Tests / A-B timing only: 0 choose, 1 hga_fused_kernel, 2 three launches (dss_selftest_hga_force_path)."""
         _lib.check(self._L.dss_selftest_hga_force_path(self._h, int(path)))
 
     def extract(self, data: np.ndarray) -> np.ndarray:

@@ -39,9 +39,10 @@ class _DecoderMixin:
 class SegmentPipeline(_DecoderMixin):
     def __init__(self, batch: int, n_samples: int = 1040, n_channels: int = 64, fs: int = 1000,
                  channel_means: Optional[np.ndarray] = None, channel_stds: Optional[np.ndarray] = None,
-                 decoder: Optional[torch.nn.Module] = None, seed: int = 0):
+                 decoder: Optional[torch.nn.Module] = None, seed: int = 0, window_length: float = 0.05,
+                 window_shift: float = 0.01):
         self.B, self.n, self.C = batch, n_samples, n_channels
-        self.hga = HgaExtractorGPU(batch, n_channels, fs=fs)
+        self.hga = HgaExtractorGPU(batch, n_channels, fs=fs, window_length=window_length, window_shift=window_shift)
         self.frames = self.hga.frames_for(n_samples)
         self.decoder = self._make_decoder(n_channels, decoder, seed)
         self.vocoder = LPCNetBatch(batch, self.frames)
@@ -50,7 +51,12 @@ class SegmentPipeline(_DecoderMixin):
         self.mean = torch.from_numpy(mean).cuda()
         self.std = torch.from_numpy(std).cuda()
         self._zs = (mean, std)
-        self._zs_in_kernel = True                             # ZScoreNormalization as the epilogue of the HGA launch
+        # ZScoreNormalization as the epilogue of the HGA launch (hga_fused_kernel's, or hga_window_kernel's when the window
+        # shape sends the extractor to its three-launch form).  Uploaded once; the intermediates tap below only switches it
+        # off and on (the library keeps the device copies: no allocation, no copy, no synchronisation per segment).
+        self._zs_in_kernel = True
+        self._zs_on = True
+        self.hga.set_zscore(mean, std)
 
     @torch.no_grad()
     def __call__(self, ecog: torch.Tensor, return_intermediates: bool = False):
@@ -58,11 +64,15 @@ class SegmentPipeline(_DecoderMixin):
         self.hga.reset()                                   # a fresh extractor per segment (prepare_corpus.py:147-176)
         self.vocoder.reset_async()                         # a fresh decoder per segment (training.py:193)
         if self._zs_in_kernel and not return_intermediates:
-            self.hga.set_zscore(*self._zs)
+            if not self._zs_on:
+                self.hga.set_zscore(*self._zs)
+                self._zs_on = True
             hga = None
             z = self.hga.extract_torch(ecog, apply_log=True).to(torch.float32)    # z-scored frames straight from the launch
         else:                                                                 # (test tap: the frames before the z-score)
-            self.hga.set_zscore(None)
+            if self._zs_on:
+                self.hga.set_zscore(None)
+                self._zs_on = False
             hga = self.hga.extract_torch(ecog, apply_log=True)                # (B, W, C) float64
             z = ((hga - self.mean) / self.std).to(torch.float32)              # ZScoreNormalization, then .float()
         feats, _ = self.decoder(z, self.decoder.create_new_initial_state(batch_size=self.B, device="cuda"))
@@ -86,12 +96,16 @@ class StreamingPipeline(_DecoderMixin):
         self._graph_out = None
         self._graph_failed = False
         self.hga_first = True            # the first packet is the frame buffer's CASE 2 (one frame): not the captured shape
+        self.last_hga = None             # test taps: the last tick's HGA frames (S, W, C) f64 and decoder output (S, W, 20) f32
+        self.last_feats = None           #   (device tensors; in graph mode the captured tick's own buffers, rewritten by every replay)
 
     @torch.no_grad()
     def _tick(self):
         hga = self.hga.extract_torch(self._in, apply_log=True)
         feats, _ = self.decoder(hga.to(torch.float32), self.decoder.create_new_initial_state(batch_size=self.S, device="cuda"))
-        return self.vocoder.synthesize_torch(feats.contiguous())
+        feats = feats.contiguous()
+        self.last_hga, self.last_feats = hga, feats
+        return self.vocoder.synthesize_torch(feats)
 
     def _capture(self):
         """Capture one steady-state tick.  Capturing enqueues nothing, so the decoder states are untouched."""
@@ -100,6 +114,7 @@ class StreamingPipeline(_DecoderMixin):
             with torch.cuda.graph(g):
                 out = self._tick()
             self._graph, self._graph_out = g, out
+            self._graph_taps = (self.last_hga, self.last_feats)
         except Exception as e:      # e.g. an RNN backend that cannot be captured: stay on eager launches
             self._graph_failed = True
             torch.cuda.synchronize()
@@ -120,6 +135,7 @@ class StreamingPipeline(_DecoderMixin):
                 self._capture()
             if self._graph is not None:
                 self._graph.replay()
+                self.last_hga, self.last_feats = self._graph_taps
                 return self._graph_out.cpu().numpy()
         pcm = self._tick()
         self.hga_first = False

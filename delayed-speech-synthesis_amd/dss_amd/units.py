@@ -68,17 +68,32 @@ class HighGammaExtractor:
         if p is not None and len(p) == 3 and hasattr(p[0], "grid_mapping") and hasattr(p[1], "selection_masks_computation") \
                 and hasattr(p[2], "speech_grid_mapping") and len(p[2].speech_grid_mapping) == nb_electrodes:
             self._fused_pre = tuple(p)
-        # decode_online.py:88-97's single post-transform, ZScoreNormalization (common.py:367-376), is recognised the same way
-        # and applied by the library right behind the log (dss_hga_set_zscore): (frames - means) / stds, the same two IEEE
-        # operations numpy performs; any other chain runs on the host as given
+        # decode_online.py:88-97's single post-transform, ZScoreNormalization (common.py:367-376), is applied by the library
+        # right behind the log (dss_hga_set_zscore): (frames - means) / stds, the same two IEEE operations numpy performs.
+        # It is recognised by what it DOES, not by its attribute names: the object is run on a probe array and must return,
+        # bit for bit, (x - channel_means) / channel_stds -- a look-alike that clips, adds an epsilon or casts keeps its own
+        # __call__ on the host, like any other chain.
         self._fused_post = False
         q = post_transforms
         if q is not None and len(q) == 1 and hasattr(q[0], "channel_means") and hasattr(q[0], "channel_stds"):
             m = np.asarray(q[0].channel_means, dtype=np.float64).reshape(-1)
             sd = np.asarray(q[0].channel_stds, dtype=np.float64).reshape(-1)
-            if m.shape == (nb_electrodes,) and sd.shape == (nb_electrodes,):
+            if m.shape == (nb_electrodes,) and sd.shape == (nb_electrodes,) and self._is_plain_zscore(q[0], m, sd):
                 self._gpu.set_zscore(m, sd)
                 self._fused_post = True
+
+    @staticmethod
+    def _is_plain_zscore(obj, m, sd) -> bool:
+        probe = np.random.default_rng(12345).standard_normal((7, m.shape[0])) * 3.0 + m
+        probe[0] = m                                           # zeros, huge and tiny values: what a clip or an epsilon would bend
+        probe[1] = m + 1e12 * sd
+        probe[2] = m - 1e-12 * sd
+        try:
+            got = np.asarray(obj(probe.copy()))
+        except Exception:
+            return False
+        want = (probe - m) / sd
+        return got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want)
 
     def extract_features(self, data: np.ndarray):
         data = np.ascontiguousarray(data, dtype=np.float64)

@@ -171,6 +171,10 @@ int dss_selftest_lin2ulaw(unsigned start_bits, unsigned stride, long n, unsigned
  * through that layout as the kernel indexes it.  info[8]: fast_path (0/1/2 as in dss_lpcnet_model_info), zr blocks max,
  * h blocks max, LDS bytes, register slots per gate on waves 4-5, tail blocks, mismatching rows, out-of-range reads. */
 int dss_selftest_fast_layout(const void *blob, size_t len, int *info);
+/* Tests and A/B timing only (process-wide): which one-utterance-per-workgroup sample kernel a call gets.  0 = choose (the
+ * packed-h form of csrc/lpcnet_sample_pkh.hip whenever the model fits it), 1 = csrc/lpcnet_sample.hip, 2 = the packed-h
+ * form or DSS_EINVAL.  Both produce the same bits. */
+int dss_selftest_lpcnet_latency_kernel(int which);
 /* Average device time (ms) of the sample-rate kernel over the calls since the last query, measured with
  * HIP events on the stream the kernel was launched on; resets the accumulator.  Needs
  * dss_lpcnet_batch_enable_timing(b, 1). */
@@ -221,12 +225,11 @@ int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, 
 /* Optional last step of the reference's feature chain inside the extractor's launch: ZScoreNormalization,
  * (frame - means[c]) / stds[c] (local/common.py:367-376; decode_online.py:88-97 puts it behind HighGammaActivity as a
  * post-transform).  means / stds: host arrays of n_channels doubles, both NULL to clear.  The device-resident entry
- * points then return z-scored frames; the host-buffer ones apply it on the host after their host-libm log.  (The
- * three-launch fallback for window shapes whose ring does not fit LDS has no epilogue: such a call fails with DSS_EINVAL.) */
+ * points then return z-scored frames (hga_fused_kernel's epilogue, or hga_window_kernel's in the three-launch form); the
+ * host-buffer ones apply it on the host after their host-libm log. */
 int dss_hga_set_zscore(dss_hga *h, const double *means, const double *stds);
 /* Tests and A/B timing only: which kernel form serves this extractor.  0 = choose (default: hga_fused_kernel; three
- * launches when its ring does not fit LDS), 1 = hga_fused_kernel, 2 = the three-launch form, 3 = hga_stream_kernel (one
- * launch from the raw packet to the z-scored frames; a multiple of 16 channels; exact, measured slower: DESIGN.md 5). */
+ * launches when its ring does not fit LDS), 1 = hga_fused_kernel, 2 = the three-launch form. */
 int dss_selftest_hga_force_path(dss_hga *h, int path);
 
 /* ------------------------------------------------------------------------------------------------

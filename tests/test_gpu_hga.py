@@ -132,16 +132,16 @@ def test_other_window_shapes_against_the_oracle(oracle, fs, wl, ws, packets):
 
 
 def test_streamed_kernel_equals_the_other_forms(golden):
-    """The three forms of the extractor -- hga_fused_kernel (default), the three launches, hga_stream_kernel (filter waves +
-    helper waves, opt-in) -- give the same bits: offline trials, 40-sample packets, ragged packets (tiles that end inside
-    a packet, packets shorter than a tile, a first packet shorter than a frame)."""
+    """The two forms of the extractor -- hga_fused_kernel (default) and the three launches (the fallback for window shapes
+    whose ring does not fit LDS) -- give the same bits: offline trials, 40-sample packets, ragged packets (tiles that end
+    inside a packet, packets shorter than a tile, a first packet shorter than a frame)."""
     import torch
     from dss_amd.hga import HgaExtractorGPU
     S = 11                                                     # not a multiple of 8: exercises the block -> stream mapping's tail
     xs = np.stack([synthetic_ecog(6000 + s, 1040, 64) for s in range(S)])
     d = torch.from_numpy(xs).cuda()
     res = {}
-    for path in (0, 2, 3):
+    for path in (0, 2):
         ex = HgaExtractorGPU(S, 64, filters=_filters(golden))
         ex._force_path(path)
         whole = ex.extract_torch(d, apply_log=False).cpu().numpy()
@@ -152,22 +152,21 @@ def test_streamed_kernel_equals_the_other_forms(golden):
             pos += n
         res[path] = (whole, np.concatenate(parts, axis=1))
     assert res[0][0].shape == (S, 100, 64)
-    for path in (2, 3):
-        assert np.array_equal(res[0][0], res[path][0]), path
-        assert np.array_equal(res[0][1], res[path][1]), path
-    g = golden("hga_frames.npz")                               # and the reference's own frames, through the streamed kernel
+    assert np.array_equal(res[0][0], res[2][0])
+    assert np.array_equal(res[0][1], res[2][1])
+    g = golden("hga_frames.npz")                               # and the reference's own frames, through the three launches
     ex = HgaExtractorGPU(4, 64, filters=_filters(golden))
-    ex._force_path(3)
+    ex._force_path(2)
     got = ex.extract(np.stack([synthetic_ecog(1000 + b, 1040, 64) for b in range(4)]))
     for b in range(4):
         assert np.array_equal(got[b], g[f"offline{b}_out"])
 
 
 def test_raw_packets_and_zscore_in_one_launch(golden):
-    """raw 129-column packets -> reorder + per-grid CAR + select -> filters -> log power -> z-score, as two
-    launches (front end, then the extractor with the z-score as its epilogue: the default) and as ONE launch
-    (hga_stream_kernel, front end inside the helper waves: opt-in).  Both equal, bit for bit, a host / torch z-score of the
-    plain frames; odd packet lengths make the raw rows start on 8-byte boundaries."""
+    """raw 129-column packets -> reorder + per-grid CAR + select -> filters -> log power -> z-score: the
+    front end, then the extractor with the z-score as its epilogue -- hga_fused_kernel's (default) or, in the three-launch
+    form, hga_window_kernel's.  Both equal, bit for bit, a host / torch z-score of the plain frames; odd packet lengths
+    make the raw rows start on 8-byte boundaries."""
     import torch
     from dss_amd.electrodes import reference_frontend
     from dss_amd.hga import HgaExtractorGPU
@@ -177,7 +176,7 @@ def test_raw_packets_and_zscore_in_one_launch(golden):
     mean, std = rng.standard_normal(64), rng.uniform(0.5, 2.0, 64)
     d = torch.from_numpy(raw).cuda()
     outs = {}
-    for path in (0, 3):
+    for path in (0, 2):
         ex = HgaExtractorGPU(S, 64, filters=_filters(golden))
         ex.set_frontend(129, *reference_frontend())
         ex._force_path(path)
@@ -186,9 +185,9 @@ def test_raw_packets_and_zscore_in_one_launch(golden):
             parts.append(ex.extract_raw_torch(d[:, pos:pos + n].contiguous(), apply_log=False).cpu().numpy())
             pos += n
         outs[path] = np.concatenate(parts, axis=1)
-    assert outs[0].shape[1] > 50 and np.array_equal(outs[0], outs[3])
+    assert outs[0].shape[1] > 50 and np.array_equal(outs[0], outs[2])
     # z-score epilogue: device-resident (log on the device) and host-buffer (glibc log) entry points, both forms
-    for path in (0, 3):
+    for path in (0, 2):
         ex = HgaExtractorGPU(S, 64, filters=_filters(golden))
         ex.set_frontend(129, *reference_frontend())
         ex._force_path(path)

@@ -54,6 +54,16 @@ def test_extractor_with_pre_and_post_transforms(golden):
     assert ex2._fused_pre is None and not ex2._fused_post
     assert np.array_equal(ex2.extract_features(raw), post(post(U.HighGammaExtractor(1000, 64).extract_features(speech(both(raw))))))
 
+    # an object that merely LOOKS like ZScoreNormalization (same attribute names, other arithmetic) keeps its own __call__
+    class Clipped(ZScore):
+        def __call__(self, x):
+            return np.clip(super().__call__(x), -2.0, 2.0)
+    clipped = Clipped(np.full((1, 64), 3.0), np.full((1, 64), 2.0))
+    ex3 = U.HighGammaExtractor(1000, 64, post_transforms=[clipped])
+    assert not ex3._fused_post
+    x3 = synthetic_ecog(79, 200, 64)
+    assert np.array_equal(ex3.extract_features(x3), clipped(U.HighGammaExtractor(1000, 64).extract_features(x3)))
+
 
 def test_vocoder_unit_segments_and_state_carry(oracle):
     import dss_amd.units as U
@@ -104,6 +114,66 @@ def test_segment_pipeline_config3(oracle, golden):
     assert np.array_equal(pcm[5].cpu().numpy(), oracle.lpcnet_utterance(m, f0))
     # segments are independent: a second call reproduces the first
     assert torch.equal(pipe(torch.from_numpy(ecog).cuda()), pcm)
+
+
+def test_segment_pipeline_window_shape_beyond_the_lds_ring(oracle):
+    """A window shape whose ring does not fit LDS (300 ms windows) sends the extractor to its three-launch form; the
+    device-resident pipeline keeps the z-score inside the launch there too (hga_window_kernel's epilogue; this shape
+    raised DSS_EINVAL on every call in round 3)."""
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import SegmentPipeline
+    lpcnet.load_model(synthetic_blob(0))
+    B = 3
+    rng = np.random.default_rng(2)
+    mean, std = rng.standard_normal(64), rng.uniform(0.5, 2.0, 64)
+    ecog = torch.from_numpy(np.stack([synthetic_ecog(300 + b, 1040, 64) for b in range(B)])).cuda()
+    pipe = SegmentPipeline(B, channel_means=mean, channel_stds=std, window_length=0.3, window_shift=0.05)
+    pcm, hga, feats = pipe(ecog, return_intermediates=True)          # frames before the z-score + host-side expression
+    assert hga.shape[1] == pipe.frames and pcm.shape == (B, pipe.frames * 160)
+    pcm2 = pipe(ecog)                                                # z-score as the launch's epilogue
+    assert torch.equal(pcm, pcm2)
+    small = SegmentPipeline(B, channel_means=mean, channel_stds=std)    # the reference's shape: the fused kernel, same contract
+    a, _, _ = small(ecog, return_intermediates=True)
+    assert torch.equal(a, small(ecog))
+
+
+def test_streaming_pipeline_config5_parity(oracle, golden):
+    """Config 5 at full size (128 streams, 40-sample packets) against the CPU side, tick by tick: stream 0 is fed the trial the
+    reference-built golden frames were made from (hga_frames.npz::online_out, Cython + scipy in the same 40-sample chunking),
+    so its HGA frames must equal them (device log: <= 1 ulp); the PCM of several streams must equal, bit for bit, one
+    oracle decoder per stream fed the device-produced features of all ticks (decoder state carried across packets,
+    units.py:524), through the eager first ticks and the graph-replayed steady state alike (decode_online.py:99-164)."""
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import StreamingPipeline
+    blob = synthetic_blob(0)
+    lpcnet.load_model(blob)
+    S, T = 128, 9
+    g = golden("hga_frames.npz")
+    x0 = synthetic_ecog(2000, 1040, 64)                        # the golden online trial
+    rng = np.random.default_rng(11)
+    sp = StreamingPipeline(S)
+    check = (0, 1, 64, 127)
+    feats = {s: [] for s in check}
+    pcm = {s: [] for s in check}
+    hga0 = []
+    for k in range(T):
+        pk = rng.standard_normal((S, 40, 64)) * 50.0
+        pk[0] = x0[40 * k:40 * k + 40]
+        out = sp.push(pk)
+        W = sp.last_hga.shape[1]
+        assert out.shape == (S, W * 160) and W == (1 if k == 0 else 4)
+        hga0.append(sp.last_hga[0].cpu().numpy())
+        f = sp.last_feats.cpu().numpy()
+        for s in check:
+            feats[s].append(f[s])
+            pcm[s].append(out[s])
+    assert sp._graph is not None                               # ticks 3.. were replayed from the captured graph
+    got = np.concatenate(hga0)
+    want = g["online_out"][:got.shape[0]]
+    assert (np.abs(got - want) / np.spacing(np.abs(want))).max() <= 1.0
+    m = oracle.lpcnet_model(blob)
+    for s in check:
+        assert np.array_equal(np.concatenate(pcm[s]), oracle.lpcnet_utterance(m, np.concatenate(feats[s]))), s
 
 
 def test_streaming_pipeline_config5():
