@@ -291,14 +291,6 @@ struct FastLayout {
     std::vector<int> unit_of, unit_h, wave_nh, grp_hoff, wave_nzr, wave_nzt;
     std::vector<float> zr_w, hblk;
     std::vector<unsigned> zr_col, h_col;
-    // packed-rows h image (lpcnet_sample_pkh.hip)
-    int pk_ok = 0, pk_floats = 0;
-    std::vector<int> pk_hoff, pk_unit, pk_nh;
-    std::vector<float> hblk_pk;
-    std::vector<unsigned> pk_hcol;
-    std::vector<int> pk_unit_of, pk_wave_nzr;
-    std::vector<float> pk_zr_w;
-    std::vector<unsigned> pk_zr_col;
 };
 
 static void build_fast_layout(const BlobView &v, int NA, FastLayout &F)
@@ -374,7 +366,7 @@ static void build_fast_layout(const BlobView &v, int NA, FastLayout &F)
             if (q && (((hfloats - grp_hoff[wv * 8 + q - 1]) / 32) & 1) == 0) hfloats += 32;
             grp_hoff[wv * 8 + q] = hfloats;
             hfloats += cnt[2 * G + grp_h[wv * 8 + q]] * 32;
-            hend = std::max(hend, grp_hoff[wv * 8 + q] + wave_nh[wv] * 32);
+            hend = std::max(hend, grp_hoff[wv * 8 + q] + (wave_nh[wv] + 4) * 32);      // + 4: the kernel fetches two chunks of two slots ahead
         }
     hfloats = std::max(hfloats, hend);                  // the last groups' over-reads stay inside the image
     // Extended paths (models with skewed sparsity only): behind the h records, the z and r tail lists of every
@@ -459,87 +451,6 @@ static void build_fast_layout(const BlobView &v, int NA, FastLayout &F)
     }
     F.fast_ok = fast_ok; F.zmax = zmax; F.hmax = hmax; F.zr_cap = zr_cap; F.ext = fast_ok ? ext : 0; F.ext_tab = ext_tab; F.hfloats = hfloats;
 
-    // ---- packed-rows h image of lpcnet_sample_pkh.hip --------------------------------------------------------------
-    // Three waves x 16 row groups; a lane carries rows q and q + 4 (q = lane & 3) of its group's blocks as the halves of
-    // packed fp32 instructions.  Record of a block: [half 2][q 4][4 floats] = (W[q][c], W[q+4][c], W[q][c+1], W[q+4][c+1]),
-    // c = 2 * half, so a lane's two ds_read_b128 of a block are 64 bytes apart and the four lanes of a group read 64
-    // consecutive bytes each time.  Lists back to back per wave (same over-read convention as above: surplus slots read on
-    // into the following records and multiply them by "column 96"); the list of group gi of a wave starts at
-    // 64 * (gi & 3) bytes modulo 256, so that the four groups of a 16-lane pass of a ds_read_b128 cover all 64 banks.
-    // Groups sorted by h block count: the wave of rank 0 gets the 16 longest lists.
-    static const int pk_rank_wave[3] = {0, 1, 2};           // h wave index: 0, 1, 2 = waves 0, 1, 5 of the kernel
-    F.pk_ok = fast_ok && hmax <= DSS_HC;
-    F.pk_hoff.assign(G, 0); F.pk_unit.assign(192, 0); F.pk_nh.assign(4, 0);
-    F.pk_hcol.assign((size_t)(DSS_HC / 4) * 192, 0u);
-    F.pk_floats = 4;
-    if (F.pk_ok) {
-        std::vector<int> pk_grp(G, 0);
-        for (int rk = 0; rk < 3; ++rk) {
-            const int wv = pk_rank_wave[rk];
-            int nh = 0;
-            for (int gi = 0; gi < 16; ++gi) {
-                pk_grp[wv * 16 + gi] = order_h[rk * 16 + gi];
-                nh = std::max(nh, cnt[2 * G + order_h[rk * 16 + gi]]);
-            }
-            F.pk_nh[wv] = (nh + 1) & ~1;
-        }
-        int pf = 0, pend = 0;
-        for (int wv = 0; wv < 3; ++wv)
-            for (int gi = 0; gi < 16; ++gi) {
-                pf += ((16 * (gi & 3) - pf) % 64 + 64) % 64;
-                F.pk_hoff[wv * 16 + gi] = pf;
-                pf += cnt[2 * G + pk_grp[wv * 16 + gi]] * 32;
-                pend = std::max(pend, F.pk_hoff[wv * 16 + gi] + (F.pk_nh[wv] + 2) * 32);     // + 2: the kernel fetches two slots ahead
-            }
-        pf = (std::max(pf, pend) + 3) & ~3;
-        F.pk_floats = pf;
-        F.hblk_pk.assign((size_t)pf, 0.f);
-        for (int tid = 0; tid < 192; ++tid) {
-            const int wv = tid / 64, gi = (tid & 63) >> 2, q = tid & 3;
-            const int grp = pk_grp[wv * 16 + gi], g = 2 * G + grp;
-            F.pk_unit[tid] = grp * 8 + q;
-            for (int sl = 0; sl < cnt[g]; ++sl) {
-                const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                float *rec = F.hblk_pk.data() + F.pk_hoff[wv * 16 + gi] + (size_t)sl * 32;
-                for (int c = 0; c < 4; ++c) {
-                    rec[(c >> 1) * 16 + q * 4 + 2 * (c & 1) + 0] = wb[c * 8 + q];
-                    rec[(c >> 1) * 16 + q * 4 + 2 * (c & 1) + 1] = wb[c * 8 + q + 4];
-                }
-                F.pk_hcol[(size_t)(sl >> 2) * 192 + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (sl & 3));
-            }
-            for (int sl = cnt[g]; sl < DSS_HC; ++sl) F.pk_hcol[(size_t)(sl >> 2) * 192 + tid] |= 96u << (8 * (sl & 3));
-        }
-    } else {
-        F.hblk_pk.assign(4, 0.f);
-    }
-    // z/r lane assignment of that kernel: its dual-FC sits on waves 2, 3, 6, 7 and its h chains on waves 0, 1, 5, so the 16 row
-    // groups with the most z/r blocks go to waves 2 and 3 (up to 10 register slots per gate), the rest to waves 4, 5, 1, 0 with
-    // 8 slots -- the lightest beside the longest h chains.  No tails: a model that needs them stays on lpcnet_sample.hip.
-    static const int pk_rank_wave_zr[6] = {2, 3, 4, 5, 1, 0};
-    F.pk_unit_of.assign(NA, 0); F.pk_wave_nzr.assign(8, 0);
-    F.pk_zr_w.assign((size_t)2 * DSS_ZRC * 4 * NA, 0.f);
-    F.pk_zr_col.assign((size_t)(2 * DSS_ZRC / 4) * NA, 0u);
-    for (int rk = 0; rk < 6 && F.pk_ok; ++rk) {
-        const int wv = pk_rank_wave_zr[rk], cap = (wv == 2 || wv == 3) ? 10 : 8;
-        int nzr = 0;
-        for (int q = 0; q < 8; ++q) nzr = std::max(nzr, std::max(cnt[order_zr[rk * 8 + q]], cnt[G + order_zr[rk * 8 + q]]));
-        if (nzr > cap) { F.pk_ok = 0; break; }
-        F.pk_wave_nzr[wv] = (nzr + 1) & ~1;
-        for (int q = 0; q < 8; ++q)
-            for (int r = 0; r < 8; ++r) {
-                const int tid = wv * 64 + q * 8 + r, grp = order_zr[rk * 8 + q];
-                F.pk_unit_of[tid] = grp * 8 + r;
-                for (int gate = 0; gate < 2; ++gate) {
-                    const int g = gate * G + grp;
-                    for (int sl = 0; sl < cnt[g]; ++sl) {
-                        const int s2 = gate * DSS_ZRC + sl;
-                        const float *wb = v.gru_a_w + (size_t)(blk0[g] + sl) * 32;
-                        for (int k = 0; k < 4; ++k) F.pk_zr_w[((size_t)s2 * 4 + k) * NA + tid] = wb[k * 8 + r];
-                        F.pk_zr_col[(size_t)(s2 >> 2) * NA + tid] |= (unsigned)(v.gru_a_idx[start[g] + sl] / 4) << (8 * (s2 & 3));
-                    }
-                }
-            }
-    }
 }
 
 static int upload_model(HostModel *hm, int device, DssModelDev &m)
@@ -644,27 +555,6 @@ static int upload_model(HostModel *hm, int device, DssModelDev &m)
         rc = dev_upload<unsigned>(zr_col.data(), zr_col.size(), &du); if (rc) return rc; m.zr_col = du;
         rc = dev_upload<unsigned>(h_col.data(), h_col.size(), &du); if (rc) return rc; m.h_col = du;
         rc = dev_upload<float>(hblk.data(), hblk.size(), &df); if (rc) return rc; m.hblk = df;
-        m.pkh_ok = F.pk_ok; m.hblk_pk_floats = F.pk_floats;
-        rc = dev_upload<float>(F.hblk_pk.data(), F.hblk_pk.size(), &df); if (rc) return rc; m.hblk_pk = df;
-        rc = dev_upload<int>(F.pk_hoff.data(), F.pk_hoff.size(), &di); if (rc) return rc; m.pk_hoff = di;
-        rc = dev_upload<int>(F.pk_unit.data(), F.pk_unit.size(), &di); if (rc) return rc; m.pk_unit = di;
-        rc = dev_upload<int>(F.pk_nh.data(), F.pk_nh.size(), &di); if (rc) return rc; m.pk_nh = di;
-        rc = dev_upload<unsigned>(F.pk_hcol.data(), F.pk_hcol.size(), &du); if (rc) return rc; m.pk_hcol = du;
-        rc = dev_upload<int>(F.pk_unit_of.data(), F.pk_unit_of.size(), &di); if (rc) return rc; m.pk_unit_of = di;
-        rc = dev_upload<int>(F.pk_wave_nzr.data(), F.pk_wave_nzr.size(), &di); if (rc) return rc; m.pk_wave_nzr = di;
-        rc = dev_upload<float>(F.pk_zr_w.data(), F.pk_zr_w.size(), &df); if (rc) return rc; m.pk_zr_w = df;
-        rc = dev_upload<unsigned>(F.pk_zr_col.data(), F.pk_zr_col.size(), &du); if (rc) return rc; m.pk_zr_col = du;
-        if (F.pk_ok) {  // embedding rows in that kernel's lane order
-            const float *tabs[3] = {v.embed_sig, v.embed_pred, v.embed_exc};
-            std::vector<float> perm((size_t)256 * NA * 3);
-            for (int t = 0; t < 3; ++t) {
-                for (int idx = 0; idx < 256; ++idx)
-                    for (int tid = 0; tid < NA; ++tid)
-                        for (int g = 0; g < 3; ++g)
-                            perm[((size_t)idx * NA + tid) * 3 + g] = tabs[t][(size_t)idx * 3 * NA + (size_t)g * NA + F.pk_unit_of[tid]];
-                rc = dev_upload<float>(perm.data(), perm.size(), &df); if (rc) return rc; m.pk_embed_lane[t] = df;
-            }
-        }
         // GRU B input weights for the two relay waves, j-major with lane = row: [384][64]
         std::vector<float> gbl((size_t)NA * 64, 0.f);
         for (int j = 0; j < NA; ++j)
@@ -1372,62 +1262,14 @@ extern "C" int dss_selftest_fast_layout(const void *blob, size_t len, int *info)
                 got.push_back(b);
             }
             compare(got, 2 * G + unit / 8, unit & 7);
+            // the kernel fetches two chunks of two slots ahead of the one it sums: those reads stay inside the image
+            if (F.grp_hoff[grp2] + (nh + 4) * 32 > F.hfloats) ++oob;
         }
     }
     for (int u = 0; u < NA; ++u) if (seen_zr[u] != 1 || seen_h[u] != 1) ++mismatches;
     if ((size_t)F.hfloats * sizeof(float) > DSS_HBLK_BYTES) ++mismatches;
-    if (F.pk_ok) {      // the packed-rows h image of lpcnet_sample_pkh.hip: rows q and q + 4 of every lane of waves 0..2
-        std::vector<int> seen_pk(NA, 0);
-        for (int tid = 0; tid < 192; ++tid) {
-            const int wave = tid / 64, q = tid & 3, nh = F.pk_nh[wave];
-            if (nh > DSS_HC || (nh & 1)) ++mismatches;
-            for (int half = 0; half < 2; ++half) {
-                const int unit = F.pk_unit[tid] + 4 * half;
-                if (unit < 0 || unit >= NA || (F.pk_unit[tid] & 7) != q) { ++mismatches; continue; }
-                ++seen_pk[unit];
-                std::vector<Blk> got;
-                for (int sl = 0; sl < nh; ++sl) {
-                    const int off = F.pk_hoff[tid >> 2] + sl * 32;
-                    if (off < 0 || off + 32 + 64 > F.pk_floats) { ++oob; continue; }     // + 2 records fetched ahead
-                    Blk b;
-                    b.col = (int)((F.pk_hcol[(size_t)(sl >> 2) * 192 + tid] >> (8 * (sl & 3))) & 0xFF);
-                    // the kernel's two ds_read_b128 of this lane: (off + q*4 .. +3) = columns 0, 1; (off + 16 + q*4 ..) = columns 2, 3
-                    for (int c = 0; c < 4; ++c) b.w[c] = F.hblk_pk[off + (c >> 1) * 16 + q * 4 + 2 * (c & 1) + half];
-                    got.push_back(b);
-                }
-                compare(got, 2 * G + unit / 8, unit & 7);
-            }
-            if (F.pk_hoff[tid >> 2] % 64 != 16 * ((tid >> 2) & 3)) ++mismatches;      // bank placement of the group's list
-        }
-        for (int u = 0; u < NA; ++u) if (seen_pk[u] != 1) ++mismatches;
-        std::vector<int> seen_pz(NA, 0);      // ... and that kernel's z/r lane assignment
-        for (int tid = 0; tid < NA; ++tid) {
-            const int wave = tid / 64, unit = F.pk_unit_of[tid], nzr = F.pk_wave_nzr[wave];
-            if (unit < 0 || unit >= NA || nzr > ((wave == 2 || wave == 3) ? 10 : 8)) { ++mismatches; continue; }
-            ++seen_pz[unit];
-            for (int gate = 0; gate < 2; ++gate) {
-                std::vector<Blk> got;
-                for (int sl = 0; sl < nzr; ++sl) {
-                    const int s2 = gate * DSS_ZRC + sl;
-                    Blk b;
-                    b.col = (F.pk_zr_col[(size_t)(s2 >> 2) * NA + tid] >> (8 * (s2 & 3))) & 0xFF;
-                    for (int k = 0; k < 4; ++k) b.w[k] = F.pk_zr_w[((size_t)s2 * 4 + k) * NA + tid];
-                    got.push_back(b);
-                }
-                compare(got, gate * G + unit / 8, unit & 7);
-            }
-        }
-        for (int u = 0; u < NA; ++u) if (seen_pz[u] != 1) ++mismatches;
-    }
     info[5] = tails / 8;             // every tail block is seen by the 8 lanes of its row group
     info[6] = mismatches; info[7] = oob;
-    return DSS_OK;
-}
-
-extern "C" int dss_selftest_lpcnet_latency_kernel(int which)
-{
-    if (which < 0 || which > 2) { dss_set_error("latency kernel: 0 (choose), 1 (lpcnet_sample.hip), 2 (lpcnet_sample_pkh.hip)"); return DSS_EINVAL; }
-    g_dss_latency_kernel = which;
     return DSS_OK;
 }
 

@@ -30,7 +30,7 @@
 #define DSS_ZR_TAIL 16        // max z (and r) blocks per row group beyond its wave's register slots
 #define DSS_HCX 32            // ... in the instantiation with the extended paths (8 VGPRs)
 #define DSS_HX 32             // max h-gate blocks per row group beyond DSS_HCX (column ids from LDS)
-#define DSS_HBLK_BYTES 138752  // dynamic LDS left after the kernel's static 24.5 KB (160 KB per CU)
+#define DSS_HBLK_BYTES 136448  // dynamic LDS left after the kernel's static 26.7 KB (160 KB per CU)
 
 void dss_set_error(const char *fmt, ...);
 
@@ -96,20 +96,6 @@ struct DssModelDev {
     const float *gb_w_lane;       // [384][64] GRU B input weights, input-major, lane = row (rows 48..63 zero)
     const float *fc_w_pair;       // dual-FC weights as [k 8][node 256][4]: (layer 0, layer 1) weights of inputs 2k, 2k+1 (pair kernel)
     const float *gb_w_quad;       // the same weights as [384/4][64 lanes][4 inputs]: one 16-byte load per lane and block of four inputs
-    // packed-rows h-gate layout of lpcnet_sample_pkh.hip: three waves, lane = rows q and q + 4 (q = lane & 3) of row group lane >> 2
-    int pkh_ok;                   // 1 when every h list fits the register-held column ids (DSS_HC)
-    int hblk_pk_floats;           // size of hblk_pk
-    const float *hblk_pk;         // LDS image: per block [half 2][q 4][(W[q][c], W[q+4][c], W[q][c+1], W[q+4][c+1])], c = 2 * half
-    const int *pk_hoff;           // [48]  per (h wave 0..2, lane / 4): float offset of that row group's records inside hblk_pk
-    const int *pk_unit;           // [192] lane of h waves 0..2 (= waves 0, 1, 5) -> GRU A unit of its first row (the second is + 4)
-    const int *pk_nh;             // [4]   per h wave 0..2: h-gate slots (even)
-    const unsigned *pk_hcol;      // [DSS_HC/4][192] four 8-bit block column ids per word
-    // ... and its own z/r lane assignment (the 16 row groups with the most z/r blocks on waves 2 and 3): same formats as
-    // unit_of / wave_nzr / zr_w / zr_col / embed_lane above
-    const int *pk_unit_of, *pk_wave_nzr;
-    const float *pk_zr_w;
-    const unsigned *pk_zr_col;
-    const float *pk_embed_lane[3];
 };
 
 // ---- per-batch device state ---------------------------------------------------------------------------
@@ -159,11 +145,6 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
 int dss_launch_sample_network_pair(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm, int trace,
                                    hipStream_t s);
 int dss_pair_fits(const DssModelDev &m);
-int dss_launch_sample_network_pkh(const DssModelDev &m, DssBatchDev &b, int n_rows, int n_frames, short *d_pcm, int trace,
-                                  hipStream_t s);
-int dss_pkh_fits(const DssModelDev &m);
-// tests / A-B timing only: 0 = choose (the packed-h form when the model fits it), 1 = lpcnet_sample.hip, 2 = lpcnet_sample_pkh.hip
-extern int g_dss_latency_kernel;
 int dss_launch_sample_network_generic(const DssModelDev &m, DssBatchDev &b, int n_utts, int n_frames, short *d_pcm,
                                       int trace, hipStream_t s);
 int dss_launch_exp10_selftest(const float *d_x, const float *d_comp, float *d_out, long n, hipStream_t s);

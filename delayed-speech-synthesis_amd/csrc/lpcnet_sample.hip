@@ -25,6 +25,7 @@
 //               the scalar recurrences: mu-law / de-emphasis / PCM bookkeeping, kiss99 thresholds, its own tree walk.
 // Summation order inside every row is exactly the C source's (one product at a time, ascending input),
 // and the library is built with -ffp-contract=off, so results are bit-identical to the scalar C path.
+#include <cstddef>
 #include <mutex>
 
 // h-gate slots DSS_HCX.. of a long list: column ids from the table behind the LDS image instead of registers, one chunk of
@@ -48,18 +49,50 @@
 #include "lpcnet_sample_common.h"
 #undef HC                                  // a constant of the role here: DSS_HC, or DSS_HCX with the extended paths
 
-#define GBH6 208                          // GRU B inputs whose weights sit in wave 6's VGPRs (0..207)
-#define GBH7 112                          // ... in wave 7's VGPRs (208..319); wave 7 also carries the scalar state
-#define GBHL (NA - GBH6 - GBH7)           // ... and the last 64 inputs' weights in LDS, [row][GBL_STRIDE]
-#define GBL_STRIDE 68
-#ifndef GBP
-#define GBP 48                            // ... of wave 7's inputs, the first GBP are multiplied while it waits for wave 6
+// GRU B: one dependent chain of 384 sums per row.  Four segments that alternate between the two relay waves; every segment
+// but the first is summed from products formed while the other wave was summing (the chain itself is then one v_add_f32
+// per input instead of 1.8 instructions):
+//   segment 1  inputs [0, GB1)            wave 6, multiplied as it goes (nothing can be formed before barrier B)
+//   segment 2  [GB1, GB1+GB2)             wave 7, products formed while wave 6 runs segment 1; weights streamed from L2 into the
+//                                         product registers (slow, but wave 6 needs 1.3 k cycles; no LDS, no extra register)
+//   segment 3  [GB1+GB2, GB1+GB2+GB3)     wave 6, products formed while wave 7 sums segment 2; weights in VGPRs
+//   segment 4  the last GB4 inputs        wave 7.  The window behind segment 2 (wave 6's GB3 sums and two hand-overs) is the
+//                                         shortest of the three and takes GB4R inputs at 6.5 cycles each (weights in VGPRs);
+//                                         the last GB4H inputs are multiplied by WAVE 4 (a GRU A wave with slack; weights in LDS)
+//                                         right after barrier B and come over through LDS.
+// Measured on the way (profiles/r4_relay_experiment.md): rounds 1-3 had two segments (208 + 176 inputs, 48 of them
+// pre-multiplied): 4.06 k cycles from barrier B to C; all of segment 4 on wave 7 stalled the chain by ~400 cycles per sample;
+// "barrier C" as an LDS word polled by the dual-FC waves was slower than the barrier (the polls take issue slots and LDS
+// cycles from the relay waves on the same SIMDs).
+#ifndef GB1
+#define GB1 144
 #endif
+#ifndef GB2
+#define GB2 96
+#endif
+#ifndef GB3
+#define GB3 48
+#endif
+#define GB4 (NA - GB1 - GB2 - GB3)
+#ifndef DSS_RELAY_MASK
+#define DSS_RELAY_MASK 1
+#endif
+#ifndef GB4H
+#define GB4H 32
+#endif
+#define GB4R (GB4 - GB4H)
+static_assert(GB4 <= GB2, "segment 4's products reuse segment 2's registers");
+static_assert(GB1 % 16 == 0 && GB2 % 8 == 0 && GB3 % 8 == 0 && GB4R % 8 == 0 && GB4H % 8 == 0 && GB4H >= 8 && GB4H <= GB4R, "segment sizes");
+#define GBL_STRIDE (GB4H + 4)             // stride = 4 mod 8: stride * row mod 64 is one-to-one on row mod 16 (the rows of a 16-lane read group hit distinct banks)
+static_assert((GBL_STRIDE % 8) == 4, "row stride: the 16 rows of a read group on distinct banks");
 struct SampleLds {
     float state_a[2][NA + 4];             // double-buffered GRU A state; "column 96" of either buffer is four zeros: the
                                           //   input of the h-gate slots a row group does not use (see DSS_H_CHAIN)
     float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
-    float gb_wl[NB3 * GBL_STRIDE];        // GRU B input weights of the last GBHL inputs, row-major
+    float gb_wl[NB3 * GBL_STRIDE];        // GRU B input weights of segment 4's last GB4H inputs, row-major (read by wave 6)
+    float gb_hp[GB4H / 4][64][4];         // ... and their products on the way from wave 4 to wave 7: [quad][lane]
+    int hp_flag;                          // number of the sample gb_hp belongs to
+    int pad0[3];
     float tansig[208];
     float ulaw2lin[256];
     float spec_tab_pred[256];             // speculation over all 256 excitation values (see role A, B..C):
@@ -68,33 +101,112 @@ struct SampleLds {
     float spec_lpc[DSS_LPC_ORDER];        //   the LPC of the next sample's frame,
     float spec_pred;                      //   and this sample's prediction
     float pad1[3];
-    float gb_acc[64];                     // GRU B partial sums handed from wave 6 to wave 7
+    float gb_acc[64][2];                  // GRU B running sums handed between the relay waves: (sum, 4 * sample number + segments done)
     float ah[NA];                         // h-gate pre-activation: written by a unit's h lane, read by its z/r lane
     float state_b[NB];
     float thr[8];
     unsigned bits[8];                     // decision bit of every tree node (256 bits)
     int idx[4];                           // last_sig_ulaw, pred_ulaw, last_exc
-    int gb_flag;                          // sequence number of the sample whose gb_acc is valid
-    int pad[3];
     short pcm[DSS_FRAME_SIZE];
 };
 
-// the same chain over the inputs whose weights live in LDS (wave 7's tail): 8 inputs per group
+// Products of a relay segment formed ahead of its sums.  Resident weights: N inputs (multiple of 16) starting at AN, weights
+// WB[WOFF..] (pairs), into PQ[0 .. N/4); the state values are read one group of 16 inputs ahead.
+#define DSS_GB_PREMUL(AN, N, WOFF, POFF)                                                               \
+    {                                                                                            \
+        f32x4 xq[2][2];                          /* eight inputs per trip: a larger buffer spilled wave 7's weights */ \
+        xq[0][0] = *reinterpret_cast<const f32x4 *>((AN));                                       \
+        xq[0][1] = *reinterpret_cast<const f32x4 *>((AN) + 4);                                   \
+        _Pragma("unroll") for (int g = 0; g < (N) / 8; ++g) {                                    \
+            if (g + 1 < (N) / 8) {                                                               \
+                xq[(g + 1) & 1][0] = *reinterpret_cast<const f32x4 *>((AN) + 8 * (g + 1));       \
+                xq[(g + 1) & 1][1] = *reinterpret_cast<const f32x4 *>((AN) + 8 * (g + 1) + 4);   \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (g + 1 < (N) / 8) DSS_WAIT_LGKM(2); else DSS_WAIT_LGKM(0);                        \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                      \
+                PQ[(POFF) + 2 * g + u].lo = WB[(WOFF) + 2 * (2 * g + u)] * xq[g & 1][u].lo;      \
+                PQ[(POFF) + 2 * g + u].hi = WB[(WOFF) + 2 * (2 * g + u) + 1] * xq[g & 1][u].hi;  \
+            }                                                                                    \
+            /* pinned: left alone, the compiler sinks the multiplications below the hand-over wait */ \
+            asm volatile("" : "+v"(PQ[(POFF) + 2 * g]), "+v"(PQ[(POFF) + 2 * g + 1]));           \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+// ... with the weights in LDS (wave 6's share of segment 4): four inputs per trip, [0] state, [1] weights
 #define DSS_GBL_LOAD(T, G)                                                                       \
     {                                                                                            \
-        T[0] = *reinterpret_cast<const f32x4 *>(al + 8 * (G));                                   \
-        T[1] = *reinterpret_cast<const f32x4 *>(al + 8 * (G) + 4);                               \
-        T[2] = *reinterpret_cast<const f32x4 *>(wl + 8 * (G));                                   \
-        T[3] = *reinterpret_cast<const f32x4 *>(wl + 8 * (G) + 4);                               \
+        T[0] = *reinterpret_cast<const f32x4 *>(al + 4 * (G));                                   \
+        T[1] = *reinterpret_cast<const f32x4 *>(wl + 4 * (G));                                   \
     }
-#define DSS_GBL_GROUP(T)                                                                         \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
-        const f32x2 p0 = T[2 + u].lo * T[u].lo;                                                  \
-        const f32x2 p1 = T[2 + u].hi * T[u].hi;                                                  \
-        acc += p0.x;                                                                             \
-        acc += p0.y;                                                                             \
-        acc += p1.x;                                                                             \
-        acc += p1.y;                                                                             \
+// ... with the weights streamed from L2 (segment 2; m.gb_w_quad: [block of four inputs][lane][4]): all N/4 loads are issued
+// up front INTO the product registers -- wave 7 has about 1.3 k idle cycles here and not one register -- and every quad is
+// then multiplied in place by its four state values.  Scalar base + lane offset + immediate per load.
+#define DSS_GBG_PREMUL(AN, N, BLK0)                                                              \
+    {                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < (N) / 4; ++g)                                      \
+            PQ[g] = *reinterpret_cast<const f32x4 *>(gq + (size_t)gvo[g >> 3] + (ptrdiff_t)(((BLK0) + g) * 1024 - ((BLK0) + (g & ~7) + 4) * 1024)); \
+        f32x4 xq[2];                                                                             \
+        xq[0] = *reinterpret_cast<const f32x4 *>((AN));                                          \
+        _Pragma("unroll") for (int g = 0; g < (N) / 4; ++g) {                                    \
+            if (g + 1 < (N) / 4) xq[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>((AN) + 4 * (g + 1)); \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            PQ[g].lo = PQ[g].lo * xq[g & 1].lo;                                                  \
+            PQ[g].hi = PQ[g].hi * xq[g & 1].hi;                                                  \
+            asm volatile("" : "+v"(PQ[g]));                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
+// The products of segment 4's last GB4H inputs, formed by a wave that is NOT in the relay (wave 4: the GRU A wave with the most
+// slack between barriers B and C; lane = GRU B row, weights from LDS) and left in LDS for wave 7, with the sample's number
+// behind them.  Neither relay wave has the time (wave 7) or the registers (wave 6: it spilled into segment 1) for them.
+#define DSS_GB_HELPER(AN, SEQ)                                                                   \
+    {                                                                                            \
+        const int hrow = lane < NB3 ? lane : 0;                                                  \
+        const float *al = (AN) + (NA - GB4H), *wl = L.gb_wl + hrow * GBL_STRIDE;                 \
+        f32x4 tq[2][2];                                                                          \
+        DSS_GBL_LOAD(tq[0], 0)                                                                   \
+        _Pragma("unroll") for (int g = 0; g < GB4H / 4; ++g) {                                   \
+            if (g + 1 < GB4H / 4) DSS_GBL_LOAD(tq[(g + 1) & 1], g + 1)                           \
+            f32x4 hp;                                                                            \
+            hp.lo = tq[g & 1][1].lo * tq[g & 1][0].lo;                                           \
+            hp.hi = tq[g & 1][1].hi * tq[g & 1][0].hi;                                           \
+            *reinterpret_cast<f32x4 *>(&L.gb_hp[g][lane][0]) = hp;                               \
+        }                                                                                        \
+        __hip_atomic_store(&L.hp_flag, (SEQ), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+    }
+// the sums of a pre-multiplied segment: one dependent chain, input order
+#define DSS_GB_SUMS(N)                                                                           \
+    {                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < (N) / 4; ++q) {                                    \
+            acc += PQ[q].x;                                                                      \
+            acc += PQ[q].y;                                                                      \
+            acc += PQ[q].z;                                                                      \
+            acc += PQ[q].w;                                                                      \
+        }                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    }
+// Hand the running sums to the other relay wave / take them over.  One 8-byte LDS word per lane carries the sum and its tag
+// (4 * sample number + segments done): the taker polls its own lane's word, and the read that sees every lane's tag has the
+// sums in it -- one LDS round trip per hand-over instead of flag, wait, sums.  Hand-written ds_ instructions: the word must be
+// written and read as ONE 8-byte access, and __builtin_bit_cast of a vector ELEMENT reads element 0 with this clang.
+#define DSS_GB_PUBLISH(V)                                                                        \
+    {                                                                                            \
+        const int tagi_ = (int)(V);                                                              \
+        const f32x2 pw_ = {acc, __builtin_bit_cast(float, tagi_)};                               \
+        asm volatile("ds_write_b64 %0, %1" :: "v"(gb_addr), "v"(pw_) : "memory");                \
+    }
+#define DSS_GB_AWAIT(V)                                                                          \
+    {                                                                                            \
+        f32x2 pv_;                                                                               \
+        unsigned tag_;                                                                           \
+        do {                                                                                     \
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pv_) : "v"(gb_addr) : "memory"); \
+            const float tf_ = pv_.y;                                                             \
+            tag_ = __builtin_bit_cast(unsigned, tf_);                                            \
+        } while (__any(tag_ != (unsigned)(V)));                                                  \
+        acc = pv_.x;                                                                             \
     }
 
 #define DSS_TREE_WALK(VAL) DSS_TREE_WALK_AT(VAL, L.bits)
@@ -126,7 +238,7 @@ struct SampleLds {
                                      __builtin_bit_cast(int, ls_lane), 0x111, 0xf, 0xf, false));  \
         last_exc = upd_exc;                                                                      \
         pcm += 0.85f * deemph;                                                                   \
-        deemph = pcm;                                                                            \
+        deemph = dss_uniform(pcm);                                                               \
         if (pcm < -32767) pcm = -32767;                                                          \
         if (pcm > 32767) pcm = 32767;                                                            \
         if (lane == 0) L.pcm[upd_i] = (short)(int)floor(.5 + (double)pcm);                       \
@@ -184,7 +296,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
     const float u2l_c = L.ulaw2lin[(HAS_FC ? 128 + tid : tid - 256) & 255];   // this lane's excitation candidate (waves 0, 1, 4, 5)
     const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
     const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;     // wave-uniform (kernel argument)
-    int cur = 0;
+    int cur = 0, seq = 0;
     float st = L.state_a[0][unit];
     unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
     f32x4 PR[2 * ZRC];                                           // z/r block products of the coming sample
@@ -289,6 +401,10 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             }
             __syncthreads();                                                        // barrier B
             if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
+            if constexpr (!HAS_FC) {
+                ++seq;
+                if (wave == 4) DSS_GB_HELPER(L.state_a[cur ^ 1], seq)            // GRU B: wave 7's last products (see DSS_GB_HELPER)
+            }
             DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
             DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
             if (wave == 5 || wave < 2) {
@@ -367,6 +483,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     __shared__ __attribute__((aligned(16))) SampleLds L;
     extern __shared__ __attribute__((aligned(16))) float hblk_lds[];       // h-gate block records (size per model)
     static_assert(sizeof(SampleLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
+    static_assert(sizeof(SampleLds) + DSS_HBLK_BYTES <= 160 * 1024, "LDS budget");
     constexpr bool RG = RAGGED || TRACE;
     // row of this call (scratch, features, PCM): ragged calls with counts start their longest rows first (b.row_of)
     const int utt = (RG && b.row_of) ? __builtin_amdgcn_readfirstlane(b.row_of[blockIdx.x]) : b.utt0 + (int)blockIdx.x;
@@ -380,16 +497,17 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     for (int k = tid * 4; k < m.hblk_floats; k += 512 * 4)
         *reinterpret_cast<f32x4 *>(&hblk_lds[k]) = *reinterpret_cast<const f32x4 *>(&m.hblk[k]);
     for (int k = tid; k < NB * NB3; k += 512) L.gb_wrec[k] = m.gru_b_w_rec[k];
-    for (int k = tid; k < NB3 * GBHL; k += 512) {
-        const int row = k / GBHL, j = k - row * GBHL;
-        L.gb_wl[row * GBL_STRIDE + j] = m.gb_w_lane[(size_t)(GBH6 + GBH7 + j) * 64 + row];
+    for (int k = tid; k < NB3 * GB4H; k += 512) {
+        const int row = k / GB4H, j = k - row * GB4H;
+        L.gb_wl[row * GBL_STRIDE + j] = m.gb_w_lane[(size_t)(NA - GB4H + j) * 64 + row];
     }
     if (tid < 201) L.tansig[tid] = m.tansig[tid];
     if (tid < 256) L.ulaw2lin[tid] = m.ulaw2lin[tid];
     if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)slot * NA + tid];
     if (tid < 8) L.state_a[tid >> 2][NA + (tid & 3)] = 0.f;
     if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)slot * NB + tid];
-    if (tid == 0) L.gb_flag = 0;
+    if (tid < 128) L.gb_acc[tid >> 1][tid & 1] = 0.f;
+    if (tid == 0) L.hp_flag = 0;
     const int fc0 = b.fc0[utt];
     __syncthreads();
 
@@ -401,16 +519,23 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         // =====================================================================================================
         // role B1: GRU B over inputs 0..207, lane = row (0..15 z, 16..31 r, 32..47 h)
         // =====================================================================================================
-        f32x2 WB[GBH6 / 2];
+        f32x2 WB[(GB1 + GB3) / 2];                   // segment 1's weights, then segment 3's
 #pragma unroll
-        for (int j = 0; j < GBH6 / 2; ++j) {
+        for (int j = 0; j < GB1 / 2; ++j) {
             WB[j].x = m.gb_w_lane[(size_t)(2 * j) * 64 + lane];
             WB[j].y = m.gb_w_lane[(size_t)(2 * j + 1) * 64 + lane];
         }
+#pragma unroll
+        for (int j = 0; j < GB3 / 2; ++j) {
+            WB[GB1 / 2 + j].x = m.gb_w_lane[(size_t)(GB1 + GB2 + 2 * j) * 64 + lane];
+            WB[GB1 / 2 + j].y = m.gb_w_lane[(size_t)(GB1 + GB2 + 2 * j + 1) * 64 + lane];
+        }
+        const unsigned gb_addr = dss_lds_addr(&L.gb_acc[lane][0]);
         const int row = lane < NB3 ? lane : 0;
         __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
         const float gbb0 = m.gru_b_bias[row];
         int cur = 0, seq = 0;
+        unsigned long long r6[4] = {0, 0, 0, 0};     // diagnostic build: cycles from barrier B to the relay's way points on this wave
         __syncthreads();                                             // matches role A's prologue barrier
         for (int f = 0; f < nf; ++f) {
             if (fc0 + f < DSS_FEATURES_DELAY) continue;
@@ -421,9 +546,25 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
                 __syncthreads();                                                        // barrier B
                 const float *an = L.state_a[cur ^ 1];
-                DSS_GB_CHAIN(an, GBH6)
-                L.gb_acc[lane] = acc;
-                __hip_atomic_store(&L.gb_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned long long t6 = 0;
+                if (STAMP) t6 = __builtin_readcyclecounter();
+#if DSS_RELAY_MASK
+                if (lane < NB3) {        // 48 rows: the other 16 lanes only cost LDS return cycles (every state read is 16 B per ACTIVE lane)
+#endif
+                DSS_GB_CHAIN(an, GB1)                                                   // segment 1, multiplied as it goes
+                DSS_GB_PUBLISH(seq * 4 + 1)
+                if (STAMP) { asm volatile("" : "+v"(acc)); r6[0] += __builtin_readcyclecounter() - t6; }
+                f32x4 PQ[GB3 / 4];
+                DSS_GB_PREMUL(an + GB1 + GB2, GB3, GB1 / 2, 0)                          // segment 3's products, while wave 7 sums segment 2
+                if (STAMP) r6[1] += __builtin_readcyclecounter() - t6;
+                DSS_GB_AWAIT(seq * 4 + 2)
+                if (STAMP) r6[2] += __builtin_readcyclecounter() - t6;
+                DSS_GB_SUMS(GB3)
+                DSS_GB_PUBLISH(seq * 4 + 3)
+                if (STAMP) { asm volatile("" : "+v"(acc)); r6[3] += __builtin_readcyclecounter() - t6; }
+#if DSS_RELAY_MASK
+                }
+#endif
                 DSS_SPECULATE(lane)                          // this wave is idle from here to barrier B: candidates 0..63
                 __syncthreads();                                                        // barrier C
                 __syncthreads();                                                        // barrier D
@@ -431,15 +572,26 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             }
         }
         __syncthreads();                                                                // final barrier
+        if (STAMP && lane == 0 && b.trace_pcm && gridDim.x == 1)
+            for (int k = 0; k < 4; ++k) b.trace_pcm[72 + k] = (float)r6[k];
     } else {
         // =====================================================================================================
         // role B2 + S (wave 7): GRU B inputs 208..383 and gates; scalar recurrences replicated across lanes
         // =====================================================================================================
-        f32x2 WB[GBH7 / 2];
+        f32x2 WB[GB4R / 2];                          // the weights of segment 4's first GB4R inputs
 #pragma unroll
-        for (int j = 0; j < GBH7 / 2; ++j) {
-            WB[j].x = m.gb_w_lane[(size_t)(GBH6 + 2 * j) * 64 + lane];
-            WB[j].y = m.gb_w_lane[(size_t)(GBH6 + 2 * j + 1) * 64 + lane];
+        for (int j = 0; j < GB4R / 2; ++j) {
+            WB[j].x = m.gb_w_lane[(size_t)(NA - GB4 + 2 * j) * 64 + lane];
+            WB[j].y = m.gb_w_lane[(size_t)(NA - GB4 + 2 * j + 1) * 64 + lane];
+        }
+        const unsigned gb_addr = dss_lds_addr(&L.gb_acc[lane][0]);
+        // segment 2's weights come from L2 every sample: lane offsets of its eight-block windows in m.gb_w_quad
+        const char *gq = reinterpret_cast<const char *>(m.gb_w_quad);
+        unsigned gvo[(GB2 / 4 + 7) / 8];
+#pragma unroll
+        for (int k = 0; k < (GB2 / 4 + 7) / 8; ++k) {
+            gvo[k] = (unsigned)lane * 16 + (unsigned)(GB1 / 4 + 8 * k + 4) * 1024u;
+            asm volatile("" : "+v"(gvo[k]));
         }
         const int row = lane < NB3 ? lane : 0;
         __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
@@ -451,7 +603,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         int last_exc = b.last_exc[slot];
         DssKiss99 rng = {b.rng[slot * 4 + 0], b.rng[slot * 4 + 1], b.rng[slot * 4 + 2], b.rng[slot * 4 + 3]};
         unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
-        unsigned long long t_prev = 0;
+        unsigned long long t_prev = 0, r7[6] = {0, 0, 0, 0, 0, 0};      // r7: cycles from barrier B to the relay's way points on this wave
         int cur = 0, seq = 0;
         float pred = 0.f, upd_pred = 0.f;
         int upd_exc = 0, upd_i = 0;
@@ -490,6 +642,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 {   // off the critical path: this sample's 8 thresholds and GRU B's recurrent half
                     const uint32_t r0 = dss_kiss99_rand(rng);
                     const uint32_t r1 = dss_kiss99_rand(rng);
+                    rng.z = dss_uniform(rng.z); rng.w = dss_uniform(rng.w); rng.jsr = dss_uniform(rng.jsr); rng.jcong = dss_uniform(rng.jcong);
                     if (lane < 8) {
                         const uint32_t r = lane < 4 ? r0 : r1;
                         L.thr[lane] = m.logit_table[(r >> (8 * (lane & 3))) & 0xFF];     // 1 KB table, L2/L1 resident
@@ -511,62 +664,44 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 const float sb_old = L.state_b[lane & (NB - 1)];     // the h lanes' own unit: read here, not after the chain
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[2] += t - t_prev; t_prev = t; }
-                // While wave 6 runs the first half of the chain, this wave forms the products of its first GBP inputs (it
-                // has about 1900 idle cycles and, until its own part of the chain starts, the registers of the prefetch
-                // buffers): when wave 6 hands over, those inputs cost one sum each instead of 1.8 instructions.
-                const float *an = L.state_a[cur ^ 1] + GBH6;
-                f32x4 PQ[GBP / 4];
+                // While wave 6 runs segment 1, this wave forms the products of segment 2 (weights from L2); while wave 6 sums
+                // segment 3, those of segment 4's first GB4R inputs into the same registers.  Its own part of the chain is sums only.
+                const float *an = L.state_a[cur ^ 1];
+#if DSS_RELAY_MASK
+                if (lane < NB3) {
+#endif
+                f32x4 PQ[GB2 / 4];
+                float acc;
+                DSS_GBG_PREMUL(an + GB1, GB2, GB1 / 4)
+                if (STAMP) r7[0] += __builtin_readcyclecounter() - t_prev;
+                while (__hip_atomic_load(&L.hp_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
+                    ;                                    // wave 4's products of this sample are in LDS (it forms them first thing after barrier B);
+                                                         //   asked here, where this wave waits for segment 1 anyway
+                DSS_GB_AWAIT(seq * 4 + 1)
+                if (STAMP) r7[1] += __builtin_readcyclecounter() - t_prev;
+                DSS_GB_SUMS(GB2)
+                DSS_GB_PUBLISH(seq * 4 + 2)
+                if (STAMP) { asm volatile("" : "+v"(acc)); r7[2] += __builtin_readcyclecounter() - t_prev; }
+                DSS_GB_PREMUL(an + (NA - GB4), GB4R, 0, 0)
+                if (STAMP) r7[3] += __builtin_readcyclecounter() - t_prev;
+                DSS_GB_AWAIT(seq * 4 + 3)
+                if (STAMP) r7[4] += __builtin_readcyclecounter() - t_prev;
+                // Segment 4: the first GB4H inputs' sums, then -- their registers being free -- the reads of wave 4's GB4H products,
+                // which land while the remaining GB4R - GB4H products are summed.
+                DSS_GB_SUMS(GB4H)
 #pragma unroll
-                for (int g = 0; g < GBP / 16; ++g) {
-                    f32x4 xq[4];
-                    DSS_GB_LOAD(xq, an, g)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        PQ[4 * g + u].lo = WB[2 * (4 * g + u)] * xq[u].lo;
-                        PQ[4 * g + u].hi = WB[2 * (4 * g + u) + 1] * xq[u].hi;
-                    }
-                    // pinned: left alone, the compiler sinks the multiplications below the hand-off wait
-                    asm volatile("" : "+v"(PQ[4 * g].x), "+v"(PQ[4 * g].y), "+v"(PQ[4 * g].z), "+v"(PQ[4 * g].w),
-                                      "+v"(PQ[4 * g + 1].x), "+v"(PQ[4 * g + 1].y), "+v"(PQ[4 * g + 1].z), "+v"(PQ[4 * g + 1].w),
-                                      "+v"(PQ[4 * g + 2].x), "+v"(PQ[4 * g + 2].y), "+v"(PQ[4 * g + 2].z), "+v"(PQ[4 * g + 2].w),
-                                      "+v"(PQ[4 * g + 3].x), "+v"(PQ[4 * g + 3].y), "+v"(PQ[4 * g + 3].z), "+v"(PQ[4 * g + 3].w));
-                }
-                f32x4 avA[4], avB[4];
-                DSS_GB_LOAD(avA, an + GBP, 0)                // first state group of the part it multiplies on the fly
+                for (int g = 0; g < GB4H / 4; ++g) PQ[g] = *reinterpret_cast<const f32x4 *>(&L.gb_hp[g][lane][0]);
                 __builtin_amdgcn_sched_barrier(0);
-                while (__hip_atomic_load(&L.gb_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
-                    ;                                    // tight poll: one LDS round trip per iteration is pause enough
-                float acc = L.gb_acc[lane];
 #pragma unroll
-                for (int q = 0; q < GBP / 4; ++q) {
+                for (int q = GB4H / 4; q < GB4R / 4; ++q) {
                     acc += PQ[q].x;
                     acc += PQ[q].y;
                     acc += PQ[q].z;
                     acc += PQ[q].w;
                 }
-                {
-                    DSS_GB_CHAIN_RUN_OFF(an + GBP, GBH7 - GBP, GBP / 2)
-                    const float *al = an + GBH7, *wl = L.gb_wl + row * GBL_STRIDE;
-                    f32x4 tA[4], tB[4];                   // [0..1] state, [2..3] weights of two groups of 4 inputs
-                    DSS_GBL_LOAD(tA, 0)
-#pragma unroll
-                    for (int g = 0; g < GBHL / 8; g += 2) {
-                        if (g + 1 < GBHL / 8) DSS_GBL_LOAD(tB, g + 1)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (g + 1 < GBHL / 8) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        DSS_GBL_GROUP(tA)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (g + 2 < GBHL / 8) DSS_GBL_LOAD(tA, g + 2)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (g + 1 < GBHL / 8) {
-                            if (g + 2 < GBHL / 8) DSS_WAIT_LGKM(4); else DSS_WAIT_LGKM(0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            DSS_GBL_GROUP(tB)
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+                __builtin_amdgcn_sched_barrier(0);
+                DSS_GB_SUMS(GB4H)                                                       // (PQ[0 .. GB4H/4) again: wave 4's products)
+                if (STAMP) { asm volatile("" : "+v"(acc)); r7[5] += __builtin_readcyclecounter() - t_prev; }
                 {   // gates: lanes 0..15 z, 16..31 r, 32..47 h.  r and z travel up to their unit's h lane with gfx950's
                     // row/half swaps (VALU) instead of ds_bpermute (an LDS round trip each, on the sample's critical
                     // path); the new state is formed in the h lanes.  Only the first result of a swap is used, with
@@ -580,6 +715,9 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     hh = dss_tanh_approx(L.tansig, hh);
                     if (lane >= 2 * NB && lane < NB3) L.state_b[lane - 2 * NB] = z_for_h * sb_old + (1 - z_for_h) * hh;
                 }
+#if DSS_RELAY_MASK
+                }
+#endif
                 __syncthreads();                                                        // barrier C
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
                 __syncthreads();                                                        // barrier D
@@ -589,12 +727,12 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 DSS_TREE_WALK(val)
                 const int exc = val;
                 // the next sample's prediction and mu-law indices were precomputed for every possible exc
-                const float pred_next = L.spec_tab_pred[exc];     // (the GRU A waves look the mu-law indices up themselves)
+                const float pred_next = dss_uniform(L.spec_tab_pred[exc]);     // (the GRU A waves look the mu-law indices up themselves)
                 have_spec = next_exists;
                 // Everything below only updates this wave's own state; except at the end of a frame (whose PCM is
                 // copied out right after the loop) it is deferred until after the next barrier A, off the path
                 // that the GRU A waves are waiting on.
-                upd_exc = exc; upd_pred = pred; upd_i = i; upd_pending = true;
+                upd_exc = exc; upd_pred = pred; upd_i = i; upd_pending = true;       // (all wave-uniform: scalar registers)
                 pred = pred_next;
                 if (i == DSS_FRAME_SIZE - 1) { DSS_S_UPDATE() }
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[5] += t - t_prev; t_prev = t; }
@@ -604,8 +742,10 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 reinterpret_cast<int *>(pcm_frame)[k] = reinterpret_cast<const int *>(L.pcm)[k];
         }
         __syncthreads();                                                                // final barrier
-        if (STAMP && lane == 0 && b.trace_pcm)          // diagnostic build only
+        if (STAMP && lane == 0 && b.trace_pcm) {        // diagnostic build only
             for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)utt * 6 + k] = (float)stamp_acc[k];
+            if (gridDim.x == 1) for (int k = 0; k < 6; ++k) b.trace_pcm[64 + k] = (float)r7[k];
+        }
         if (lane < NB) b.gru_b_state[(size_t)slot * NB + lane] = L.state_b[lane];
         if (lane < DSS_LPC_ORDER) b.last_sig[(size_t)slot * DSS_LPC_ORDER + lane] = ls_lane;
         if (lane == 0) {
@@ -615,8 +755,6 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         }
     }
 }
-
-int g_dss_latency_kernel = 0;
 
 // Number of CUs of the current device, asked once per device (the eager streaming tick launches this kernel every 40 ms).
 static int dss_cu_count()
@@ -656,14 +794,6 @@ int dss_launch_sample_network(const DssModelDev &m, DssBatchDev &b, int n_utts, 
         b.utt0 = n_pair;
     }
     const int n_rows = n_utts - n_pair;          // rows of this launch
-    // One utterance per workgroup: the packed-h form (lpcnet_sample_pkh.hip) for every model it fits; the kernel below for
-    // models with extended paths or 12 z/r register slots (g_dss_latency_kernel: tests and A/B timing)
-    if (g_dss_latency_kernel != 1 && dss_pkh_fits(m)) {
-        const int rc = dss_launch_sample_network_pkh(m, b, n_rows, n_frames, d_pcm, trace, s);
-        b.utt0 = 0;
-        return rc;
-    }
-    if (g_dss_latency_kernel == 2) { b.utt0 = 0; dss_set_error("the packed-h kernel does not fit this model"); return DSS_EINVAL; }
     const size_t dyn = ((size_t)m.hblk_floats * sizeof(float) + 15) & ~(size_t)15;
     // two register-slot capacities are compiled: 10 per gate (no spills) and 12 (a few spilled registers)
     const bool z10 = m.zr_cap <= 10;

@@ -15,6 +15,17 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// a value every lane holds alike, moved to a scalar register (the relay waves have no vector register to spare)
+__device__ __forceinline__ float dss_uniform(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+__device__ __forceinline__ int dss_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t dss_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// LDS byte address of an object in the workgroup's LDS (for the hand-written ds_ instructions below)
+__device__ __forceinline__ unsigned dss_lds_addr(const void *p)
+{
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p;
+}
+
 
 // where DSS_H_CHAIN leaves the finished h-gate pre-activation of unit `uh` (the including kernel may redefine it)
 #ifndef DSS_H_STORE
@@ -80,24 +91,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         ah += p0.x; ah += p0.y; ah += p1.x; ah += p1.y;                                          \
         ah += p2.x; ah += p2.y; ah += p3.x; ah += p3.y;                                          \
     }
+// Chunks C (in HA) and C + 1 (into HB), C even; on entry the operands of chunk C are in flight.  The operands of the next
+// two chunks are fetched UNCONDITIONALLY whenever chunk C exists -- past the end of a wave's lists they are the following
+// records times "column 96" (the image is padded by four records), never used -- so that every path into a MAC has the
+// same number of LDS reads outstanding behind the ones it needs and the compiler waits with lgkmcnt(4).  With the
+// fetches under their own tests (rounds 1-3) half of the MACs waited with lgkmcnt(0): the full LDS latency, seven times
+// per 28-slot list and sample.
+#define DSS_H_PAIR(C)                                                                            \
+    if constexpr (2 * (C) < HC) {                                                                \
+        if (2 * (C) < nh) {                                                                      \
+            DSS_H_LOAD(HB, (2 * ((C) + 1) < HC ? (C) + 1 : 0))                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_H_MAC(HA)                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            DSS_H_LOAD(HA, (2 * ((C) + 2) < HC ? (C) + 2 : 0))                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            if (2 * ((C) + 1) < nh) {                                                            \
+                DSS_H_MAC(HB)                                                                    \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
+    }
 #define DSS_H_CHAIN(XBUF)                                                                        \
     {                                                                                            \
         const char *xbase = reinterpret_cast<const char *>(XBUF);                                \
         f32x4 HA[4], HB[4];                                                                      \
         float ah = rbh + dgh * (XBUF)[uh];                                                       \
         DSS_H_LOAD(HA, 0)                                                                        \
-        _Pragma("unroll") for (int c = 0; c < HC / 2; c += 2) {                                  \
-            if (2 * c >= nh) break;                                                              \
-            if (2 * (c + 1) < nh) DSS_H_LOAD(HB, c + 1)                                          \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-            DSS_H_MAC(HA)                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-            if (2 * (c + 1) >= nh) break;                                                        \
-            if (2 * (c + 2) < nh) DSS_H_LOAD(HA, c + 2)                                          \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-            DSS_H_MAC(HB)                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-        }                                                                                        \
+        DSS_H_PAIR(0) DSS_H_PAIR(2) DSS_H_PAIR(4) DSS_H_PAIR(6) DSS_H_PAIR(8) DSS_H_PAIR(10) DSS_H_PAIR(12) DSS_H_PAIR(14) \
+        static_assert(HC <= 32, "add DSS_H_PAIR terms");                                         \
         DSS_H_TAIL                                                                               \
         DSS_H_STORE(ah);                                                                         \
     }

@@ -43,7 +43,6 @@ def _declare(L):
         "dss_selftest_exp10": (i, [vp, vp, vp, C.c_long]),
         "dss_selftest_lin2ulaw": (i, [C.c_uint, C.c_uint, C.c_long, vp]),
         "dss_selftest_fast_layout": (i, [vp, C.c_size_t, vp]),
-        "dss_selftest_lpcnet_latency_kernel": (i, [i]),
         "dss_lpcnet_load_model": (i, [C.c_char_p, sz]),
         "dss_lpcnet_load_model_file": (i, [C.c_char_p]),
         "dss_lpcnet_bytes_per_sample": (C.c_double, []),

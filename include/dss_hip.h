@@ -171,10 +171,6 @@ int dss_selftest_lin2ulaw(unsigned start_bits, unsigned stride, long n, unsigned
  * through that layout as the kernel indexes it.  info[8]: fast_path (0/1/2 as in dss_lpcnet_model_info), zr blocks max,
  * h blocks max, LDS bytes, register slots per gate on waves 4-5, tail blocks, mismatching rows, out-of-range reads. */
 int dss_selftest_fast_layout(const void *blob, size_t len, int *info);
-/* Tests and A/B timing only (process-wide): which one-utterance-per-workgroup sample kernel a call gets.  0 = choose (the
- * packed-h form of csrc/lpcnet_sample_pkh.hip whenever the model fits it), 1 = csrc/lpcnet_sample.hip, 2 = the packed-h
- * form or DSS_EINVAL.  Both produce the same bits. */
-int dss_selftest_lpcnet_latency_kernel(int which);
 /* Average device time (ms) of the sample-rate kernel over the calls since the last query, measured with
  * HIP events on the stream the kernel was launched on; resets the accumulator.  Needs
  * dss_lpcnet_batch_enable_timing(b, 1). */

@@ -29,6 +29,8 @@ def child(path):
     L.dss_lpcnet_load_model.argtypes = [C.c_char_p, C.c_size_t]
     blob = synthetic_blob(0)
     assert L.dss_lpcnet_load_model(blob, len(blob)) == 0
+    if os.environ.get("AB_LATENCY_KERNEL") and hasattr(L, "dss_selftest_lpcnet_latency_kernel"):     # builds of the round-4 experiment
+        assert L.dss_selftest_lpcnet_latency_kernel(int(os.environ["AB_LATENCY_KERNEL"])) == 0      #   (tools/experiments/) carry two latency kernels
     B, F = int(os.environ.get("AB_BATCH", "256")), 100         # AB_BATCH=1024: the two-utterances-per-workgroup kernel
     feats = torch.from_numpy(np.stack([synthetic_features(b, F) for b in range(B)])).cuda()
     out = torch.empty((B, F * 160), dtype=torch.int16, device="cuda")

@@ -65,6 +65,7 @@ struct PkhLds {
     short pcm[DSS_FRAME_SIZE];
 };
 static_assert(sizeof(PkhLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
+static_assert(offsetof(PkhLds, c_flag) == offsetof(PkhLds, state_b) + 64, "c_flag directly behind state_b");
 static_assert(sizeof(PkhLds) + DSS_PKH_HBLK_BYTES <= 160 * 1024, "LDS budget");
 
 // ---- packed-rows h chain ----------------------------------------------------------------------------------------------
@@ -176,11 +177,6 @@ __device__ __forceinline__ f32x2 dss_qh_chain(const char *xbase, const char *hw,
         }                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     }
-// LDS byte address of an object in the workgroup's LDS (for the hand-written ds_ instructions below)
-__device__ __forceinline__ unsigned dss_lds_addr(const void *p)
-{
-    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p;
-}
 // Hand the running sums to the other relay wave / take them over.  One 8-byte LDS word per lane carries the sum and its
 // tag (8 * sample number + stages done): the taker polls its own lane's word, and the read that sees every lane's tag has
 // the sums in it -- one LDS round trip per hand-over instead of flag, wait, sums.  Hand-written ds_ instructions: a
@@ -275,33 +271,6 @@ __device__ __forceinline__ void dss_pkh_fc(PkhLds &L, const PkhFc &fc, const Dss
     const unsigned long long mask = __ballot(bit);
     if (lane == 0) { L.bits[2 * k] = (unsigned)mask; L.bits[2 * k + 1] = (unsigned)(mask >> 32); }
 }
-// "Barrier C": wait until wave 7 has published GRU B's state of sample `seq`, and return that state.  The word sits behind
-// the state and is read FIRST: LDS operations of a wave complete in order, on the writing side (state, then word) and on
-// the reading side, so the read that finds the word has the new state behind it -- one LDS round trip.
-__device__ __forceinline__ void dss_pkh_await_c(PkhLds &L, int seq, f32x4 (&bq)[NB / 4])
-{
-    static_assert(NB == 16 && offsetof(PkhLds, c_flag) == offsetof(PkhLds, state_b) + 64, "c_flag directly behind state_b");
-    const unsigned a = dss_lds_addr(L.state_b);
-    int flag;
-    do {
-        asm volatile("ds_read_b32 %0, %5 offset:64\n\t"
-                     "ds_read_b128 %1, %5\n\t"
-                     "ds_read_b128 %2, %5 offset:16\n\t"
-                     "ds_read_b128 %3, %5 offset:32\n\t"
-                     "ds_read_b128 %4, %5 offset:48\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(flag), "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]) : "v"(a) : "memory");
-    } while (flag != seq);
-}
-// wave 7's side of it: the new state (lanes 32..47), then the word -- in this order, no wait in between
-__device__ __forceinline__ void dss_pkh_publish_c(PkhLds &L, int lane, float new_state, int seq)
-{
-    const unsigned a = dss_lds_addr(L.state_b) + (unsigned)(lane & (NB - 1)) * 4;
-    const unsigned af = dss_lds_addr(&L.c_flag);
-    if (lane >= 2 * NB && lane < NB3) asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(new_state) : "memory");
-    asm volatile("ds_write_b32 %0, %1" :: "v"(af), "v"(seq) : "memory");
-}
-
 // wave 7: fold the sampled excitation into the signal history and emit the PCM sample (lpcnet_synthesize_tail_impl)
 #define DSS_QS_UPDATE()                                                                          \
     {                                                                                            \
@@ -468,7 +437,7 @@ __device__ __forceinline__ void dss_pkh_role_a(PkhLds &L, float *hblk_lds, const
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
                 if constexpr (ROLE == ROLE_FC) {
                     f32x4 bq[NB / 4];
-                    dss_pkh_await_c(L, seq, bq);                                    // "barrier C": GRU B's new state
+                    dss_await_c(L.state_b, seq, bq);                                    // "barrier C": GRU B's new state
                     if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
                     dss_pkh_fc<TRACE>(L, fc, b, bq, node, fck, lane, ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + i);
                 }
@@ -586,7 +555,7 @@ lpcnet_sample_pkh_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__re
                 dss_pkh_speculate(L, lane, u2l_c);           // candidates 0..63, while wave 7 runs the last stage and the gates
                 if (STAMP) atc6 += __builtin_readcyclecounter() - t6;
                 f32x4 bq[NB / 4];
-                dss_pkh_await_c(L, seq, bq);                                            // "barrier C"
+                dss_await_c(L.state_b, seq, bq);                                            // "barrier C"
                 dss_pkh_fc<TRACE>(L, fc, b, bq, 128 + lane, 2, lane, ((size_t)utt * n_frames + f) * DSS_FRAME_SIZE + i);
                 __syncthreads();                                                        // barrier D
                 cur ^= 1;
@@ -709,7 +678,7 @@ lpcnet_sample_pkh_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__re
                     const float z_for_h = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(0u, zb, false, false)[0]);      // 32..47 <- 0..15
                     float hh = acc + rec * r_for_h;
                     hh = dss_tanh_approx(L.tansig, hh);
-                    dss_pkh_publish_c(L, lane, z_for_h * sb_old + (1 - z_for_h) * hh, seq);      // "barrier C"
+                    dss_publish_c(L.state_b, lane, z_for_h * sb_old + (1 - z_for_h) * hh, seq);      // "barrier C"
                 }
                 if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
                 __syncthreads();                                                        // barrier D

@@ -27,6 +27,12 @@ print("  min/max total over utterances:", st.sum(axis=1).min(), st.sum(axis=1).m
 if MODE == 2 and B == 1:                                   # one workgroup: the relay waves' own stamps inside B..C
     print(f"  GRU B relay, from barrier B: wave 6 hands over for the last time at {raw[65] / n:.1f} and reaches C at {raw[66] / n:.1f}, "
           f"wave 7 ends the chain at {raw[64] / n:.1f} and reaches C at {raw[67] / n:.1f}")
+if MODE == 1 and B == 1:      # one workgroup: the relay waves' own way points inside B..C
+    w7 = raw[64:70] / n
+    w6 = raw[72:76] / n
+    print(f"  GRU B relay, cycles from barrier B: wave 6 segment 1 summed + published {w6[0]:.0f} | wave 7 segment 2 products ready {w7[0]:.0f}, "
+          f"has the sums {w7[1]:.0f}, segment 2 summed + published {w7[2]:.0f} | wave 6 segment 3 products ready {w6[1]:.0f}, has the sums {w6[2]:.0f}, "
+          f"summed + published {w6[3]:.0f} | wave 7 segment 4 products ready {w7[3]:.0f}, has the sums {w7[4]:.0f}, summed {w7[5]:.0f}")
 rawA = np.empty((F * 160,), np.float32)
 chunks = []
 for k in range((B * 48 + rawA.size - 1) // rawA.size):
