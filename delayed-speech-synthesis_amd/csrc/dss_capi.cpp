@@ -1740,3 +1740,112 @@ extern "C" int dss_gate_frames_seen(dss_gate *g, int stream)
     if (hipMemcpy(&v, g->d.state + (size_t)stream * DSS_GATE_STATE_INTS + 7, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return DSS_ENODEV;
     return v;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// neural voice-activity detector (Part 5 of include/dss_hip.h; csrc/vad_lstm.hip)
+// ------------------------------------------------------------------------------------------------------
+struct dss_vad {
+    int device;
+    DssVadDev d;
+    float *w[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // wT0, b0, wT1, b1, wc, bc
+    bool loaded = false;
+};
+
+extern "C" dss_vad *dss_vad_create(int n_streams, int n_inputs, int hidden_units)
+{
+    if (n_streams <= 0 || n_inputs <= 0 || hidden_units <= 0) { dss_set_error("VAD dims must be positive"); return nullptr; }
+    if (ensure_device()) return nullptr;
+    dss_vad *v = new dss_vad;
+    memset(&v->d, 0, sizeof(v->d));
+    v->device = g_device;
+    v->d.S = n_streams; v->d.C = n_inputs; v->d.H = hidden_units;
+    const size_t n = (size_t)2 * n_streams * hidden_units;
+    if (dev_alloc<float>(n, &v->d.h) || dev_alloc<float>(n, &v->d.c) || hipMemset(v->d.h, 0, n * sizeof(float)) != hipSuccess ||
+        hipMemset(v->d.c, 0, n * sizeof(float)) != hipSuccess) {
+        dss_set_error("device allocation failed for the VAD state");
+        dss_vad_destroy(v);
+        return nullptr;
+    }
+    return v;
+}
+
+extern "C" void dss_vad_destroy(dss_vad *v)
+{
+    if (!v) return;
+    hipSetDevice(v->device);
+    for (float *p : v->w) if (p) hipFree(p);
+    if (v->d.h) hipFree(v->d.h);
+    if (v->d.c) hipFree(v->d.c);
+    delete v;
+}
+
+// torch.nn.LSTM parameter layout (host arrays): weight_ih_l0 [4H][C], weight_hh_l0 [4H][H], bias_ih_l0 / bias_hh_l0 [4H],
+// weight_ih_l1 [4H][H], weight_hh_l1 [4H][H], bias_ih_l1 / bias_hh_l1 [4H], classifier weight [2][H] and bias [2]
+extern "C" int dss_vad_load_weights(dss_vad *v, const float *w_ih0, const float *w_hh0, const float *b_ih0, const float *b_hh0,
+                                    const float *w_ih1, const float *w_hh1, const float *b_ih1, const float *b_hh1,
+                                    const float *cls_w, const float *cls_b)
+{
+    if (!v || !w_ih0 || !w_hh0 || !b_ih0 || !b_hh0 || !w_ih1 || !w_hh1 || !b_ih1 || !b_hh1 || !cls_w || !cls_b) {
+        dss_set_error("dss_vad_load_weights: null argument"); return DSS_EINVAL;
+    }
+    DSS_HIP_CHECK(hipSetDevice(v->device));
+    const int C = v->d.C, H = v->d.H, H4 = 4 * H, Cp = (C + 3) & ~3, Hp = (H + 3) & ~3;
+    // the kernel's copies: [inputs / 4][4H rows][4 consecutive inputs], input counts padded to multiples of 4 with zero weights
+    std::vector<float> t0((size_t)(Cp + Hp) * H4, 0.f), t1((size_t)2 * Hp * H4, 0.f), b0(H4), b1(H4);
+    auto put = [&](std::vector<float> &t, int k, int r, float w) { t[((size_t)(k >> 2) * H4 + r) * 4 + (k & 3)] = w; };
+    for (int r = 0; r < H4; ++r) {
+        for (int k = 0; k < C; ++k) put(t0, k, r, w_ih0[(size_t)r * C + k]);
+        for (int k = 0; k < H; ++k) put(t0, Cp + k, r, w_hh0[(size_t)r * H + k]);
+        for (int k = 0; k < H; ++k) put(t1, k, r, w_ih1[(size_t)r * H + k]);
+        for (int k = 0; k < H; ++k) put(t1, Hp + k, r, w_hh1[(size_t)r * H + k]);
+        b0[r] = b_ih0[r] + b_hh0[r];
+        b1[r] = b_ih1[r] + b_hh1[r];
+    }
+    for (float *&p : v->w) { if (p) hipFree(p); p = nullptr; }
+    int rc = dev_upload<float>(t0.data(), t0.size(), &v->w[0]);
+    rc |= dev_upload<float>(b0.data(), b0.size(), &v->w[1]);
+    rc |= dev_upload<float>(t1.data(), t1.size(), &v->w[2]);
+    rc |= dev_upload<float>(b1.data(), b1.size(), &v->w[3]);
+    rc |= dev_upload<float>(cls_w, (size_t)2 * H, &v->w[4]);
+    rc |= dev_upload<float>(cls_b, 2, &v->w[5]);
+    if (rc) return DSS_ENOMEM;
+    v->d.wT0 = v->w[0]; v->d.b0 = v->w[1]; v->d.wT1 = v->w[2]; v->d.b1 = v->w[3]; v->d.wc = v->w[4]; v->d.bc = v->w[5];
+    v->loaded = true;
+    return DSS_OK;
+}
+
+// zero the recurrent state of one stream (create_new_initial_state, models.py:22-24), or of all (stream < 0)
+extern "C" int dss_vad_reset(dss_vad *v, int stream)
+{
+    if (!v || stream >= v->d.S) { dss_set_error("bad VAD / stream"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(v->device));
+    const size_t SH = (size_t)v->d.S * v->d.H, H = v->d.H;
+    for (float *p : {v->d.h, v->d.c}) {
+        if (stream < 0) { DSS_HIP_CHECK(hipMemset(p, 0, 2 * SH * sizeof(float))); continue; }
+        for (int layer = 0; layer < 2; ++layer) DSS_HIP_CHECK(hipMemset(p + layer * SH + (size_t)stream * H, 0, H * sizeof(float)));
+    }
+    return DSS_OK;
+}
+
+// d_frames: (S, n_frames, C) float64 (frames_are_f64, as the extractor returns them) or float32; d_labels: (S, n_frames) int32;
+// d_logits: (S, n_frames, 2) float32 or NULL.  All device pointers; asynchronous on hip_stream.
+extern "C" int dss_vad_step_dev(dss_vad *v, const void *d_frames, int frames_are_f64, int n_frames, int *d_labels, float *d_logits,
+                                void *hip_stream)
+{
+    if (!v || !d_frames || !d_labels || n_frames <= 0) { dss_set_error("dss_vad_step_dev: bad arguments"); return DSS_EINVAL; }
+    if (!v->loaded) { dss_set_error("dss_vad_step_dev: no weights loaded (dss_vad_load_weights)"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(v->device));
+    return dss_launch_vad(v->d, d_frames, frames_are_f64, n_frames, d_labels, d_logits, (hipStream_t)hip_stream);
+}
+
+// host copies of the recurrent state, [2 layers][S][H] each (either may be NULL); set == 0 reads, set != 0 writes
+extern "C" int dss_vad_state(dss_vad *v, float *h, float *c, int set)
+{
+    if (!v) return DSS_EINVAL;
+    DSS_HIP_CHECK(hipSetDevice(v->device));
+    const size_t n = (size_t)2 * v->d.S * v->d.H * sizeof(float);
+    DSS_HIP_CHECK(hipDeviceSynchronize());
+    if (h) DSS_HIP_CHECK(set ? hipMemcpy(v->d.h, h, n, hipMemcpyHostToDevice) : hipMemcpy(h, v->d.h, n, hipMemcpyDeviceToHost));
+    if (c) DSS_HIP_CHECK(set ? hipMemcpy(v->d.c, c, n, hipMemcpyHostToDevice) : hipMemcpy(c, v->d.c, n, hipMemcpyDeviceToHost));
+    return DSS_OK;
+}

@@ -168,6 +168,19 @@ struct DssGateDev {
 int dss_launch_gate(const DssGateDev &g, const double *d_frames, const int *d_labels, int W, hipStream_t s);
 int dss_launch_gate_reset(const DssGateDev &g, int stream, hipStream_t s);
 
+// ---- neural voice-activity detector (vad_lstm.hip) -----------------------------------------------------------
+struct DssVadDev {
+    int S, C, H;                  // streams, inputs per frame, hidden units (two LSTM layers, two classes)
+    const float *wT0;             // [(Cp + Hp) / 4][4H][4]: weight_ih_l0 then weight_hh_l0, four consecutive inputs of a row side by
+                                  //   side, input counts padded to multiples of 4 (gate order i, f, g, o)
+    const float *b0;              // [4H]  bias_ih_l0 + bias_hh_l0
+    const float *wT1;             // [2 Hp / 4][4H][4]: weight_ih_l1 then weight_hh_l1
+    const float *b1;              // [4H]
+    const float *wc, *bc;         // classifier [2][H], [2]
+    float *h, *c;                 // [2 layers][S][H] each
+};
+int dss_launch_vad(const DssVadDev &v, const void *d_frames, int frames_f64, int W, int *d_labels, float *d_logits, hipStream_t s);
+
 struct DssHgaDev {
     int S, C, fs, nsec;
     float wl, ws;

@@ -68,6 +68,12 @@ def _declare(L):
         "dss_gate_segment": (i, [vp, i, i, vp, i]),
         "dss_gate_segment_dev": (i, [vp, i, i, vp, i, vp]),
         "dss_gate_frames_seen": (i, [vp, i]),
+        "dss_vad_create": (vp, [i, i, i]),
+        "dss_vad_destroy": (None, [vp]),
+        "dss_vad_load_weights": (i, [vp] * 11),
+        "dss_vad_reset": (i, [vp, i]),
+        "dss_vad_step_dev": (i, [vp, vp, i, i, vp, vp, vp]),
+        "dss_vad_state": (i, [vp, vp, vp, i]),
         "dss_hga_num_windows": (i, [i, i, f, f]),
         "dss_hga_log_power": (i, [vp, i, i, i, f, f, vp]),
         "dss_hga_create": (vp, [i, i, i, f, f, i, vp, vp, vp, vp]),

@@ -162,7 +162,7 @@ class GatedStreamingPipeline(_DecoderMixin):
                  buffer_size: int = 2000, context_frames: int = 50, smoothing_context: int = 5,
                  channel_means: Optional[np.ndarray] = None, channel_stds: Optional[np.ndarray] = None,
                  decoder: Optional[torch.nn.Module] = None, vad: Optional[torch.nn.Module] = None, seed: int = 0,
-                 max_segment_frames: Optional[int] = None):
+                 max_segment_frames: Optional[int] = None, use_vad_kernel: bool = True):
         self.S, self.C, self.packet = n_streams, n_channels, packet
         self.hga = HgaExtractorGPU(n_streams, n_channels, fs=fs)
         self.decoder = self._make_decoder(n_channels, decoder, seed)
@@ -171,7 +171,12 @@ class GatedStreamingPipeline(_DecoderMixin):
             torch.manual_seed(seed + 1)     # no trained checkpoint exists offline: seeded random weights
             vad = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=n_channels)
         self.vad = vad.eval().cuda()
-        self.vad_state = self.vad.create_new_initial_state(batch_size=n_streams, device="cuda")
+        # The reference's detector (2-layer LSTM + linear head, models.py:11-33) runs as ONE launch per tick on the library's own
+        # kernel (dss_vad_step_dev: all streams, all frames of the packet, state carried in HBM); any other module is called as
+        # given, on PyTorch-ROCm.
+        from . import vad as _vad
+        self.vad_gpu = _vad.VadLstmGPU(n_streams, self.vad) if (use_vad_kernel and _vad.fits(self.vad)) else None
+        self.vad_state = None if self.vad_gpu else self.vad.create_new_initial_state(batch_size=n_streams, device="cuda")
         max_w = packet // max(1, int(0.01 * fs)) + 1      # frames one packet can complete (10 ms shift)
         self.gate = SpeechGateGPU(n_streams, n_channels, buffer_size, context_frames, smoothing_context, 0.6, max_frames=max_w)
         self.seg_cap = int(max_segment_frames or buffer_size)
@@ -198,8 +203,11 @@ class GatedStreamingPipeline(_DecoderMixin):
             return []
         # post-transform (ZScoreNormalization): already applied inside the launch when the channel count allows
         z = hga if self._zs_in_kernel else ((hga - self.mean) / self.std).contiguous()
-        logits, self.vad_state = self.vad(z.to(torch.float32), self.vad_state)       # units.py:433-434
-        labels = torch.argmax(logits, dim=2).to(torch.int32).contiguous()
+        if self.vad_gpu is not None:                                                 # units.py:433-434 in one launch
+            labels = self.vad_gpu.step_torch(z)
+        else:
+            logits, self.vad_state = self.vad(z.to(torch.float32), self.vad_state)
+            labels = torch.argmax(logits, dim=2).to(torch.int32).contiguous()
         self.last_labels, self.last_z = labels, z
         events = self.gate.push_torch(z, labels)
         self.frame_counter += W

@@ -262,6 +262,34 @@ int dss_gate_segment_dev(dss_gate *g, int stream, int event, float *d_dst, int c
 /* Frames this stream has been pushed since the last reset (FilterSpeechSegments' frame_counter). */
 int dss_gate_frames_seen(dss_gate *g, int stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Part 5 -- the neural voice-activity detector in front of the gate, for n_streams streams:
+ * UnidirectionalVoiceActivityDetector (local/models.py:11-33: LSTM(n_inputs -> H) -> LSTM(H -> H) -> Linear(H -> 2)) as
+ * FilterSpeechSegments.process calls it (local/units.py:432-434): every frame of a packet, (h, c) of both layers carried
+ * across packets, label = argmax of the two logits.  One launch per call (csrc/vad_lstm.hip).  The reference's arithmetic
+ * here is torch.nn.LSTM's: results agree with it to ~1e-6 on the logits (tested at 2e-5), not bit for bit.
+ * decode_online.py:115-121 builds the model with 2 layers x 150 hidden units over 64 high-gamma features.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dss_vad dss_vad;
+dss_vad *dss_vad_create(int n_streams, int n_inputs, int hidden_units /* <= 160 */);
+void dss_vad_destroy(dss_vad *v);
+/* Host arrays in torch.nn.LSTM's own layout (state_dict of the reference class, gate order i, f, g, o):
+ * lstm.weight_ih_l0 [4H][n_inputs], lstm.weight_hh_l0 [4H][H], lstm.bias_ih_l0 / bias_hh_l0 [4H], the same four for l1
+ * ([4H][H]), classifier.weight [2][H], classifier.bias [2]. */
+int dss_vad_load_weights(dss_vad *v, const float *w_ih0, const float *w_hh0, const float *b_ih0, const float *b_hh0,
+                         const float *w_ih1, const float *w_hh1, const float *b_ih1, const float *b_hh1,
+                         const float *cls_w, const float *cls_b);
+/* Zero state (create_new_initial_state, models.py:22-24) of one stream, or of all (stream < 0). */
+int dss_vad_reset(dss_vad *v, int stream);
+/* All streams advance by n_frames.  Device pointers, enqueued on hip_stream: d_frames (n_streams, n_frames, n_inputs)
+ * float64 (frames_are_f64 != 0: as dss_hga_extract_dev returns them; cast to float32 like units.py:433) or float32;
+ * d_labels (n_streams, n_frames) int32, 1 = speech -- what dss_gate_push_dev takes; d_logits (n_streams, n_frames, 2)
+ * float32 or NULL. */
+int dss_vad_step_dev(dss_vad *v, const void *d_frames, int frames_are_f64, int n_frames, int *d_labels, float *d_logits,
+                     void *hip_stream);
+/* Host copies of the recurrent state, [2 layers][n_streams][H] each, either may be NULL; set == 0 reads, else writes. */
+int dss_vad_state(dss_vad *v, float *h, float *c, int set);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,86 @@ def test_gated_streaming_pipeline_against_per_stream_composition(oracle):
             assert a.dtype == np.int16 and np.array_equal(a, b), k
         n_seg += len(want)
     assert n_seg >= 6
+
+
+def test_vad_kernel_matches_the_reference_golden_and_torch(golden):
+    """Row f4's LSTM(150) x 2 step kernel (csrc/vad_lstm.hip) against the reference's own detector: the golden logits that
+    /root/reference's UnidirectionalVoiceActivityDetector produced (oracle/make_golden.py: torch.manual_seed(1), two packets
+    of four frames, state carried) within 2e-5, and on random frames for 128 streams the labels (and logits, 2e-5) of
+    torch.nn.LSTM running the same weights on the GPU, over several packets with carried state."""
+    from dss_amd.models import UnidirectionalVoiceActivityDetector
+    from dss_amd.vad import VadLstmGPU, fits
+    g = golden("models.npz")
+    torch.manual_seed(1)                                   # the seed the golden vector's weights were drawn with
+    m = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64).eval()
+    assert fits(m) and sum(p.numel() for p in m.parameters()) == int(g["vad_params"][0])
+    x = torch.from_numpy(g["bilstm_in"]).cuda()            # (1, 100, 64) float32: the golden run used its first 8 frames
+    k = VadLstmGPU(1, m)
+    l1, y1 = k.step_torch(x[:, :4], want_logits=True)
+    l2, y2 = k.step_torch(x[:, 4:8].to(torch.float64), want_logits=True)      # the float64 entry casts like units.py:433
+    got = torch.cat([y1, y2], dim=1).cpu().numpy()
+    assert np.abs(got - g["vad_out"]).max() <= 2e-5
+    assert np.array_equal(torch.cat([l1, l2], dim=1).cpu().numpy(), g["vad_out"].argmax(axis=2).astype(np.int32))
+    # 128 streams x packets of 4, 1, 5 and 4 frames against torch.nn.LSTM on the same device, state carried by both
+    S = 128
+    mg = m.cuda()
+    k = VadLstmGPU(S, mg)
+    state = mg.create_new_initial_state(batch_size=S, device="cuda")
+    rng = np.random.default_rng(9)
+    n_close = 0
+    for w in (4, 1, 5, 4, 4):
+        z = torch.from_numpy(rng.standard_normal((S, w, 64)) * 2.0).cuda()
+        with torch.no_grad():
+            want, state = mg(z.to(torch.float32), state)
+        labels, logits = k.step_torch(z, want_logits=True)
+        assert (logits - want).abs().max().item() <= 2e-5
+        margin = (want[..., 1] - want[..., 0]).abs()
+        sure = margin > 1e-4                               # a tie within the tolerance may fall either way
+        n_close += int((~sure).sum())
+        assert torch.equal(labels[sure], want.argmax(dim=2).to(torch.int32)[sure])
+    assert n_close < 20
+    h, c = k.state()
+    assert np.abs(h - state[0].cpu().numpy()).max() <= 2e-5 and np.abs(c - state[1].cpu().numpy()).max() <= 1e-4
+    # a stream's state can be cleared on its own
+    k.reset(3)
+    h2, c2 = k.state()
+    assert not h2[:, 3].any() and not c2[:, 3].any() and np.array_equal(h2[:, 4], h[:, 4])
+
+
+def test_gated_pipeline_with_the_vad_kernel_equals_the_torch_detector():
+    """GatedStreamingPipeline with the reference's detector: the kernel path (default) and the PyTorch-ROCm module give the
+    same labels and therefore the same segments and PCM."""
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import GatedStreamingPipeline
+    lpcnet.load_model(synthetic_blob(0))
+    from dss_amd.models import UnidirectionalVoiceActivityDetector
+    S, C = 6, 64
+    rng = np.random.default_rng(21)
+    # stretches of loud and quiet input and a detector whose two logits are mirror images (w1 = -w0, no bias), so that its
+    # decision follows the sign of one projection of the LSTM state and both labels occur
+    env = np.repeat(np.where(rng.random((S, 60)) < 0.5, 3.0, 60.0), 20, axis=1)          # (S, 1200)
+    ecog = rng.standard_normal((S, 1200, C)) * env[:, :, None]
+    pk = [ecog[:, 40 * k:40 * k + 40] for k in range(30)]
+    mean = np.full(C, 5.0)
+
+    def detector():
+        torch.manual_seed(5)
+        m = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=C)
+        with torch.no_grad():
+            m.classifier.weight[1] = -m.classifier.weight[0]
+            m.classifier.bias.zero_()
+        return m
+    kw = dict(buffer_size=300, context_frames=8, max_segment_frames=300, channel_means=mean)
+    a = GatedStreamingPipeline(S, C, vad=detector(), **kw)
+    b = GatedStreamingPipeline(S, C, vad=detector(), use_vad_kernel=False, **kw)
+    assert a.vad_gpu is not None and b.vad_gpu is None
+    n_labels = 0
+    for p in pk:
+        ga, gb = a.push(p), b.push(p)
+        la, lb = a.last_labels.cpu().numpy(), b.last_labels.cpu().numpy()
+        assert np.array_equal(la, lb)                     # (a logit tie within 1e-6 could differ; none occurs with this seed)
+        n_labels += int(la.sum())
+        assert [(s, q) for s, q, _ in ga] == [(s, q) for s, q, _ in gb]
+        for (_, _, x), (_, _, y) in zip(ga, gb):
+            assert np.array_equal(x, y)
+    assert 0 < n_labels < S * 30 * 4                      # the seeded detector says both things
