@@ -68,16 +68,18 @@ def _hga_job(args):
 
 
 def cpu_baseline(utt_per_core=2):
-    """LPCNet and HGA on the GPU box's host cores: `cores`-process pool (the reference's pattern) and ONE core."""
+    """LPCNet and HGA on the GPU box's host cores: `cores`-process pool (the reference's pattern) and ONE core.
+    Pool figures = total work / wall time of the pool.map call, for both legs (a figure built from the jobs' own spans moved
+    6x when one job was descheduled); the spans are kept as a secondary field."""
     import multiprocessing as mp
     so = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "all"], stdout=subprocess.DEVNULL)
     try:
-        cores = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))              # GPU-box share for one GPU
+        affinity = os.cpu_count() or 1
+    cores = max(1, min(affinity, 16))           # GPU-box share for one GPU
     n_utts = cores * utt_per_core
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
@@ -85,25 +87,59 @@ def cpu_baseline(utt_per_core=2):
         t0 = time.time()
         samples = sum(pool.map(_cpu_job, [(s, FRAMES) for s in range(n_utts)], chunksize=1))
         dt = time.time() - t0
-        # HGA: 1.04-s x 64-channel trials (config 3's unit), 8 per job
-        hga_res = pool.map(_hga_job, [(1000 + 8 * j, 8) for j in range(cores)], chunksize=1)
+        # HGA: 1.04-s x 64-channel trials (config 3's unit), 8 per job, two jobs per worker
+        pool.map(_hga_job, [(900, 1)] * cores)                      # warm (filter tables, first call)
+        t0 = time.time()
+        hga_res = pool.map(_hga_job, [(1000 + 8 * j, 8) for j in range(2 * cores)], chunksize=1)
+        dth = time.time() - t0
     _cpu_job((10_001, 3))
     t0 = time.time()
     one = sum(_cpu_job((s, FRAMES)) for s in range(4))              # four 1-s utterances on ONE core (this process)
     dt1 = time.time() - t0
     sec1, t1 = _hga_job((2000, 8))
-    hga_pool = sum(r[0] for r in hga_res) / max(r[1] for r in hga_res)
-    return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+    hga_seconds = sum(r[0] for r in hga_res)
+    host = {"os_cpu_count": os.cpu_count(), "affinity_cores": affinity, "pool_size": cores}
+    return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port", "host": host,
             "sample": f"{n_utts} x 1-s utterances (seeds 0..{n_utts - 1}), one utterance per pool job, "
-                      f"{cores}-process pool, oracle/liboracle.so (scalar C, gcc -O2 generic)",
+                      f"{cores}-process pool, oracle/liboracle.so (scalar C, gcc -O2 generic); total samples / wall time of the pool.map call",
             "x_realtime": samples / dt / 16000.0,
             "one_core": {"value": one / dt1, "unit": "samples/s", "cores": 1, "x_realtime": one / dt1 / 16000.0,
                          "sample": "4 x 1-s utterances (seeds 0..3) in one process"},
-            "hga": {"value": hga_pool, "unit": "stream-seconds/s (64 ch @ 1 kHz)", "cores": cores, "kind": "port",
-                    "sample": f"{8 * cores} trials of 1.04 s x 64 ch, fresh filter state per trial, {cores}-process pool, "
+            "hga": {"value": hga_seconds / dth, "unit": "stream-seconds/s (64 ch @ 1 kHz)", "cores": cores, "kind": "port",
+                    "sample": f"{16 * cores} trials of 1.04 s x 64 ch, fresh filter state per trial, 8 per pool job, {cores}-process pool, "
                               "oracle/liboracle.so (DF2T cascade + frame buffer + log power; bit-equal to the reference's "
-                              "scipy sosfilt + Cython chain)",
+                              "scipy sosfilt + Cython chain); total stream-seconds / wall time of the pool.map call",
+                    "sum_over_slowest_job_span": hga_seconds / max(r[1] for r in hga_res),
                     "one_core": {"value": sec1 / t1, "unit": "stream-seconds/s", "cores": 1, "sample": "8 trials, one process"}}}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Dry run of the N > 1 branch (tests/test_cpu_distributed.py): DSS_BENCH_DRY=1 replaces the GPU, the library and RCCL by
+# CPU tensors, a stand-in synthesiser and gloo -- everything else (step / fence / MAX over ranks / the JSON line) is the
+# code the first multi-GPU run executes.
+# ---------------------------------------------------------------------------------------------------------
+DRY = os.environ.get("DSS_BENCH_DRY") == "1"
+
+
+class _DryDecoder:
+    """Stand-in for LPCNetBatch: deterministic int16 from the features, on the CPU."""
+
+    def reset_async(self):
+        pass
+
+    def synthesize_torch(self, feats, out=None):
+        import torch
+        pcm = (feats[:, :, :1] * 1000.0).to(torch.int16).expand(-1, -1, FRAME).reshape(feats.shape[0], -1)
+        if out is not None:
+            out.copy_(pcm)
+            return out
+        return pcm
+
+    def enable_timing(self, on):
+        pass
+
+    def kernel_ms(self, which):
+        return 1.0
 
 
 def main():
@@ -138,22 +174,35 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from dss_amd import _lib, lpcnet
     from dss_amd.lpcnet_weights import synthetic_features
 
-    torch.cuda.set_device(local_rank)
-    _lib.check(_lib.require_gpu().dss_set_device(local_rank))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     B = args.batch
-    lpcnet.load_model(synthetic=True)           # seeded synthetic weights, explicitly (no checkpoint can be fetched offline)
-    feats = torch.from_numpy(np.stack([synthetic_features(rank * B + b, FRAMES) for b in range(B)])).cuda()
-    out = torch.empty((B, FRAMES * FRAME), dtype=torch.int16, device="cuda")
-    dec = lpcnet.LPCNetBatch(B, FRAMES, device=local_rank)
-    info = lpcnet.model_info()
-    cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    if DRY:                                     # CPU tensors, gloo, a stand-in synthesiser: see _DryDecoder
+        dev = "cpu"
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        dec = _DryDecoder()
+        info = {"fast_path": 1, "h_lds_bytes": 0, "kernel": "stand-in (DSS_BENCH_DRY=1)"}
+        cus = 256
+
+        def sync():
+            pass
+    else:
+        from dss_amd import _lib, lpcnet
+        dev = "cuda"
+        torch.cuda.set_device(local_rank)
+        _lib.check(_lib.require_gpu().dss_set_device(local_rank))
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        lpcnet.load_model(synthetic=True)       # seeded synthetic weights, explicitly (no checkpoint can be fetched offline)
+        dec = lpcnet.LPCNetBatch(B, FRAMES, device=local_rank)
+        info = lpcnet.model_info()
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        sync = torch.cuda.synchronize
+    feats = torch.from_numpy(np.stack([synthetic_features(rank * B + b, FRAMES) for b in range(B)])).to(dev)
+    out = torch.empty((B, FRAMES * FRAME), dtype=torch.int16, device=dev)
 
     def kernel_for(n_utts):     # the library's own rule (csrc/lpcnet_sample.hip dss_launch_sample_network)
         pair = info["fast_path"] == 1 and info["h_lds_bytes"] <= 144896 and n_utts > max(128, cus)
@@ -172,7 +221,7 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(args.warmup):
         step()
@@ -183,7 +232,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -192,13 +241,14 @@ def main():
     dec.enable_timing(True)
     for _ in range(max(3, min(args.steps, 10))):
         step()
-    torch.cuda.synchronize()
+    sync()
     k_ms, f_ms = dec.kernel_ms(0), dec.kernel_ms(1)
     dec.enable_timing(False)
 
+    extras = rank == 0 and world == 1 and not args.no_latency and not DRY      # the other configs' legs: N = 1 only
     # the kernel a model with skewed sparsity lands on: the generic sample-rate kernel, same batch, N=1 only
     generic = None
-    if rank == 0 and world == 1 and not args.no_latency:
+    if extras:
         dec.enable_trace(16)                    # development switch: force the generic kernel (no tracing)
         step(); torch.cuda.synchronize()
         tg = time.perf_counter()
@@ -210,12 +260,12 @@ def main():
         generic = {"kernel": "lpcnet_sample_generic_kernel", "ms_per_step": tg * 1e3, "value": B * FRAMES * FRAME / tg,
                    "unit": "samples/s", "note": "GRU A blocks streamed from L2 every sample: what a model runs on whose sparsity is "
                    "too skewed even for the CU-resident kernel's tail paths (over 16 z/r blocks of a row group beyond its register "
-                   "slots, over 64 h blocks, or an LDS image over 138752 B); dss_lpcnet_model_info reports it, "
+                   "slots, over 64 h blocks, or an LDS image over 136448 B); dss_lpcnet_model_info reports it, "
                    "profiles/r2_model_fit.txt has the steps in between"}
 
     # BASELINE.json configs[3], one GPU's share: 1024 utterances in one call (two utterances per workgroup beyond one per CU)
     config4 = None
-    if rank == 0 and world == 1 and not args.no_latency:
+    if extras:
         B4 = 1024
         f4 = torch.from_numpy(np.stack([synthetic_features(b, FRAMES) for b in range(B4)])).cuda()
         o4 = torch.empty((B4, FRAMES * FRAME), dtype=torch.int16, device="cuda")
@@ -244,7 +294,7 @@ def main():
 
     # The bulk callers' real shape (local/training.py:182-198): files of different lengths, one ragged call, rows in arrival order
     ragged = None
-    if rank == 0 and world == 1 and not args.no_latency:
+    if extras:
         Br = 1024
         counts = np.random.default_rng(0).integers(50, 301, Br)              # 0.5 .. 3 s
         fmax = int(counts.max())
@@ -270,7 +320,7 @@ def main():
 
     # BASELINE.json configs[2]: 64 segments of 64-channel ECoG (1.04 s) -> HGA -> z-score -> BiLSTM -> LPCNet -> PCM
     config3 = None
-    if rank == 0 and world == 1 and not args.no_latency:
+    if extras:
         from dss_amd.pipeline import SegmentPipeline
         from dss_amd.synthetic import synthetic_ecog
         B3 = 64
@@ -291,7 +341,7 @@ def main():
 
     # second half of BASELINE.json's metric: ECoG -> audio latency of the streaming mode (config 5), N=1 only
     latency = None
-    if rank == 0 and world == 1 and not args.no_latency:
+    if extras:
         from dss_amd.pipeline import StreamingPipeline
         sp = StreamingPipeline(128)
         sp.measure_latency(10)
@@ -303,11 +353,77 @@ def main():
                              "stream back on the host (steady-state tick replayed from a captured HIP graph); structural floor of the reference (0.55 s + whole-segment "
                              "synthesis) not included"}
 
+    # The streaming mode AS decode_online.py RUNS IT (row f4): HighGammaActivity -> FilterSpeechSegments (neural VAD on the library's
+    # kernel + smoothing + segment ring) -> whole-segment BiLSTM -> LPCNet, 128 streams; a tick on which no segment closes and a
+    # tick on which at least one does are different things, so they are reported apart
+    latency_gated = None
+    if extras:
+        from dss_amd.models import UnidirectionalVoiceActivityDetector
+        from dss_amd.pipeline import GatedStreamingPipeline
+        S, ticks = 128, 375                                          # 15 s of stream time
+        rng = np.random.default_rng(1)
+        # loud / quiet stretches of 0.2 .. 1 s per stream, and a seeded detector whose two logits mirror each other, so that
+        # its decision follows the input and both labels occur (no trained checkpoint exists offline)
+        env = np.empty((S, ticks * 40))
+        for s_ in range(S):
+            t_, loud = 0, bool(rng.integers(2))
+            while t_ < env.shape[1]:
+                n_ = int(rng.integers(200, 1000))
+                env[s_, t_:t_ + n_] = 60.0 if loud else 3.0
+                loud, t_ = not loud, t_ + n_
+        torch.manual_seed(5)
+        vad = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64)
+        with torch.no_grad():
+            vad.classifier.weight[1] = -vad.classifier.weight[0]
+            vad.classifier.bias.zero_()
+        gp = GatedStreamingPipeline(S, 64, channel_means=np.full(64, 5.0), vad=vad, max_segment_frames=400)
+        quiet, closing, n_seg, seg_frames = [], [], 0, 0
+        for k in range(ticks):
+            pk = rng.standard_normal((S, 40, 64)) * env[:, 40 * k:40 * k + 40, None]
+            t0 = time.perf_counter()
+            got = gp.push(pk)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            if k < 10:
+                continue
+            (closing if got else quiet).append(ms)
+            n_seg += len(got)
+            seg_frames += sum(len(pcm) // FRAME for _, _, pcm in got)
+        pct = lambda a, q: float(np.percentile(a, q)) if len(a) else None
+        latency_gated = {"config": "128 streams x 40-sample packets through HGA -> VAD LSTM(150)x2 (csrc/vad_lstm.hip, one launch) -> gate kernel -> "
+                                   "event counts on the host; a closing segment adds its whole-segment BiLSTM and a ragged LPCNet launch (single-"
+                                   "utterance speed); seeded detector, loud / quiet synthetic input",
+                         "ticks": ticks - 10, "stream_seconds": (ticks - 10) * 0.04,
+                         "no_segment_closing": {"ticks": len(quiet), "p50_ms": pct(quiet, 50), "p99_ms": pct(quiet, 99)},
+                         "segment_closing": {"ticks": len(closing), "p50_ms": pct(closing, 50), "p99_ms": pct(closing, 99),
+                                             "segments": n_seg, "mean_segment_frames": (seg_frames / n_seg) if n_seg else None},
+                         "vad_kernel": gp.vad_gpu is not None}
+        del gp
+
+    # Level 1 of the drop-in: what an UNCHANGED decode_online.py pays per 10 ms frame -- LPCNet.LPCNet().synthesize()
+    # through the xiph ABI (lpcnet_synthesize: one state, one frame, host in / host out; replayed from a per-state HIP graph)
+    level1 = None
+    if extras:
+        import LPCNet as _L1
+        net = _L1.LPCNet()
+        f1 = synthetic_features(1, 660)
+        for t_ in range(60):
+            net.synthesize(f1[t_])
+        l1 = []
+        for t_ in range(60, 660):
+            t0 = time.perf_counter()
+            net.synthesize(f1[t_])
+            l1.append((time.perf_counter() - t0) * 1e3)
+        level1 = {"call": "LPCNet.LPCNet().synthesize(features[20]) -> int16[160] (extensions/lpcnet/LPCNet.pyx:30-40 surface, local/units.py:534-535 caller)",
+                  "calls": len(l1), "p50_ms": float(np.percentile(l1, 50)), "p99_ms": float(np.percentile(l1, 99)),
+                  "x_realtime": 10.0 / float(np.percentile(l1, 50))}
+        del net
+
     # HBM traffic and issue counters of the dominant kernel per launch: PMC counters cannot be read from inside this
     # process, so they come from the committed rocprofv3 --pmc passes of this same command (profiles/), and are quoted
     # only for the workload they were taken on
     traffic, counters = None, None
-    tag = {256: "r3_b256", 1024: "r3_b1024"}.get(B)
+    tag = {256: "r4_b256", 1024: "r4_b1024"}.get(B)
     try:
         with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
             traffic = float(json.load(f)["hbm_bytes_per_launch_corrected"]) / 1e9          # GB per launch
@@ -322,7 +438,7 @@ def main():
     if rank == 0:
         samples_per_step = world * B * FRAMES * FRAME
         value = samples_per_step * args.steps / dt
-        bps = lpcnet.bytes_per_sample()                          # ~273 kB per output sample
+        bps = 273218.5 if DRY else lpcnet.bytes_per_sample()     # ~273 kB per output sample
         synth = B * (FRAMES - 2) * FRAME                         # samples the sample-rate kernel really computes per launch
         # SURVEY.md 8(d) "algorithmic flops": 2 per weight touched (sparse blocks, diagonal, GRU B, the 8 visited dual-FC
         # nodes) + the embedding adds; every one of them is a separate fp32 multiply or add (no FMA by contract)
@@ -356,7 +472,7 @@ def main():
         line = {
             "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not DRY else "DRY RUN (DSS_BENCH_DRY=1): stand-in synthesiser on CPU, not a measurement",
             "config": {"workload": (f"configs[1]: LPCNet-only, batch={B}" if world == 1 else
                                     f"configs[3]: LPCNet batch={world * B} sharded over {world} GPUs, {B}")
                                    + " synthetic 1-s utterances per GPU (100x20 f32 features -> "
@@ -375,6 +491,8 @@ def main():
             "config3": config3,
             "cpu_baseline": cpu,
             "latency": latency,
+            "latency_gated": latency_gated,
+            "level1": level1,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

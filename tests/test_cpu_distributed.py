@@ -56,3 +56,25 @@ def test_two_rank_gloo_gather(tmp_path, oracle):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GATHER_OK" in out.stdout
+
+
+def test_bench_multi_gpu_branch_dry_run():
+    """bench.py's own N > 1 branch -- step() with distributed.gather_pcm, fence(), the MAX all-reduce over ranks and the JSON
+    assembly -- run as two ranks under gloo with a stand-in synthesiser (DSS_BENCH_DRY=1), so that the first RCCL run on
+    real GPUs executes only code that has run before (BASELINE config 4's sharded gather)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DSS_BENCH_DRY="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "6"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 prints ONE JSON line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    cfg = line["config"]
+    assert cfg["world_size"] == 2 and cfg["batch_per_gpu"] == 6
+    assert cfg["gathered_bytes_per_step"] == 2 * 6 * 100 * 160 * 2          # both shards' int16 PCM arrived on rank 0
+    assert line["value"] > 0 and abs(line["samples_per_s_per_gpu"] * 2 - line["value"]) < 1e-6 * line["value"]
+    assert "DRY RUN" in line["data"]                          # and says so: not a measurement
