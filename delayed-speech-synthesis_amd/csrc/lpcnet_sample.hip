@@ -47,7 +47,9 @@
         }                                                                                        \
     }
 #include "lpcnet_sample_common.h"
-#undef HC                                  // a constant of the role here: DSS_HC, or DSS_HCX with the extended paths
+#undef HC
+// diagnostic build: the low 32 bits of the shader clock (differences of stamps; 64-bit accumulators cost the stamped build registers)
+#define DSS_NOW() ((unsigned)__builtin_readcyclecounter())                                  // a constant of the role here: DSS_HC, or DSS_HCX with the extended paths
 
 // GRU B: one dependent chain of 384 sums per row.  Four segments that alternate between the two relay waves; every segment
 // but the first is summed from products formed while the other wave was summing (the chain itself is then one v_add_f32
@@ -298,7 +300,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
     const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;     // wave-uniform (kernel argument)
     int cur = 0, seq = 0;
     float st = L.state_a[0][unit];
-    unsigned long long sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
+    unsigned sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0;   // diagnostic build only
     f32x4 PR[2 * ZRC];                                           // z/r block products of the coming sample
     bool first_sample = true;
     DSS_H_CHAIN(L.state_a[0])                                    // first sample of this call
@@ -337,7 +339,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             // wave-uniform by construction: keep them scalar, so that the row offsets are SALU work and the loads take an
             // SGPR base (the first-sample path would otherwise drag them into VGPRs)
             si = __builtin_amdgcn_readfirstlane(si); pi = __builtin_amdgcn_readfirstlane(pi); ei = __builtin_amdgcn_readfirstlane(ei);
-            if (STAMP) ta = __builtin_readcyclecounter();
+            if (STAMP) ta = DSS_NOW();
             {
                 // the nine embedding values of this lane: three 12-byte loads from the lane-ordered copies of the tables
                 // (m.embed_lane: [index][lane][gate]), 768 contiguous bytes per wave and table
@@ -346,14 +348,14 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 const f32x3 ep = *reinterpret_cast<const f32x3 *>(m.embed_lane[1] + ((unsigned)pi * NA + (unsigned)tid) * 3);
                 const f32x3 ee = *reinterpret_cast<const f32x3 *>(m.embed_lane[2] + ((unsigned)ei * NA + (unsigned)tid) * 3);
                 const float es0 = es.x, es1 = es.y, es2 = es.z, ep0 = ep.x, ep1 = ep.y, ep2 = ep.z, ee0 = ee.x, ee1 = ee.y, ee2 = ee.z;
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[0] += t - ta; ta = t; }
+                if (STAMP) { const unsigned t = DSS_NOW(); sa[0] += t - ta; ta = t; }
                 const float gz = ((cz + es0) + ep0) + ee0;                          // compute_gru_a_input
                 const float gr = ((cr + es1) + ep1) + ee1;
                 const float gh = ((ch + es2) + ep2) + ee2;
                 // nnet.c 2021 (default): (bias + diag*state) + input, then the blocks in idx order;
                 // nnet.c 2019-20 (blob flag): the blocks first, the input last
                 if (!recur_first) { az = az + gz; ar = ar + gr; }
-                if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[1] += t - ta; ta = t; }
+                if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); const unsigned t = DSS_NOW(); sa[1] += t - ta; ta = t; }
                 // the block products were formed right after the previous sample's state update (under GRU B);
                 // what is left on the critical path are the dependent sums, z and r chains interleaved
 #pragma unroll
@@ -390,17 +392,17 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                     }
                 }
                 if (recur_first) { az = gz + az; ar = gr + ar; }
-                if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); unsigned long long t = __builtin_readcyclecounter(); sa[2] += t - ta; ta = t; }
+                if (STAMP) { asm volatile("" :: "v"(az), "v"(ar)); const unsigned t = DSS_NOW(); sa[2] += t - ta; ta = t; }
                 float z, r;
                 dss_sigmoid_approx2(L.tansig, az, ar, z, r);
                 float h = ahv * r + gh;
                 h = dss_tanh_approx(L.tansig, h);
                 st = z * st + (1 - z) * h;
                 L.state_a[cur ^ 1][unit] = st;
-                if (STAMP) { asm volatile("" :: "v"(st)); unsigned long long t = __builtin_readcyclecounter(); sa[3] += t - ta; ta = t; }
+                if (STAMP) { asm volatile("" :: "v"(st)); const unsigned t = DSS_NOW(); sa[3] += t - ta; ta = t; }
             }
             __syncthreads();                                                        // barrier B
-            if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[4] += t - ta; ta = t; }
+            if (STAMP) { const unsigned t = DSS_NOW(); sa[4] += t - ta; ta = t; }
             if constexpr (!HAS_FC) {
                 ++seq;
                 if (wave == 4) DSS_GB_HELPER(L.state_a[cur ^ 1], seq)            // GRU B: wave 7's last products (see DSS_GB_HELPER)
@@ -423,9 +425,9 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 L.spec_tab_pred[cand] = pc;
                 L.spec_tab_idx[cand] = (unsigned short)(su_c | (pu_c << 8));
             }
-            if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[5] += t - ta; ta = t; }
+            if (STAMP) { const unsigned t = DSS_NOW(); sa[5] += t - ta; ta = t; }
             __syncthreads();                                                        // barrier C
-            if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[6] += t - ta; ta = t; }
+            if (STAMP) { const unsigned t = DSS_NOW(); sa[6] += t - ta; ta = t; }
             if constexpr (HAS_FC) {                                                 // sample_mdense, all nodes
                 const float thr_lv = L.thr[level];                                  // issued first, used last
                 f32x2 s12 = {fb0, fb1};
@@ -463,7 +465,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 if (lane == 0) { L.bits[2 * wave] = (unsigned)mask; L.bits[2 * wave + 1] = (unsigned)(mask >> 32); }
             }
             __syncthreads();                                                        // barrier D
-            if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); sa[7] += t - ta; ta = t; }
+            if (STAMP) { const unsigned t = DSS_NOW(); sa[7] += t - ta; ta = t; }
             cur ^= 1;
         }
     }
@@ -535,7 +537,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
         const float gbb0 = m.gru_b_bias[row];
         int cur = 0, seq = 0;
-        unsigned long long r6[4] = {0, 0, 0, 0};     // diagnostic build: cycles from barrier B to the relay's way points on this wave
+        unsigned r6[4] = {0, 0, 0, 0};     // diagnostic build: cycles from barrier B to the relay's way points on this wave
         __syncthreads();                                             // matches role A's prologue barrier
         for (int f = 0; f < nf; ++f) {
             if (fc0 + f < DSS_FEATURES_DELAY) continue;
@@ -546,22 +548,22 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
                 __syncthreads();                                                        // barrier B
                 const float *an = L.state_a[cur ^ 1];
-                unsigned long long t6 = 0;
-                if (STAMP) t6 = __builtin_readcyclecounter();
+                unsigned t6 = 0;
+                if (STAMP) t6 = DSS_NOW();
 #if DSS_RELAY_MASK
                 if (lane < NB3) {        // 48 rows: the other 16 lanes only cost LDS return cycles (every state read is 16 B per ACTIVE lane)
 #endif
                 DSS_GB_CHAIN(an, GB1)                                                   // segment 1, multiplied as it goes
                 DSS_GB_PUBLISH(seq * 4 + 1)
-                if (STAMP) { asm volatile("" : "+v"(acc)); r6[0] += __builtin_readcyclecounter() - t6; }
+                if (STAMP) { asm volatile("" : "+v"(acc)); r6[0] += DSS_NOW() - t6; }
                 f32x4 PQ[GB3 / 4];
                 DSS_GB_PREMUL(an + GB1 + GB2, GB3, GB1 / 2, 0)                          // segment 3's products, while wave 7 sums segment 2
-                if (STAMP) r6[1] += __builtin_readcyclecounter() - t6;
+                if (STAMP) r6[1] += DSS_NOW() - t6;
                 DSS_GB_AWAIT(seq * 4 + 2)
-                if (STAMP) r6[2] += __builtin_readcyclecounter() - t6;
+                if (STAMP) r6[2] += DSS_NOW() - t6;
                 DSS_GB_SUMS(GB3)
                 DSS_GB_PUBLISH(seq * 4 + 3)
-                if (STAMP) { asm volatile("" : "+v"(acc)); r6[3] += __builtin_readcyclecounter() - t6; }
+                if (STAMP) { asm volatile("" : "+v"(acc)); r6[3] += DSS_NOW() - t6; }
 #if DSS_RELAY_MASK
                 }
 #endif
@@ -602,8 +604,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         float deemph = b.deemph[slot];
         int last_exc = b.last_exc[slot];
         DssKiss99 rng = {b.rng[slot * 4 + 0], b.rng[slot * 4 + 1], b.rng[slot * 4 + 2], b.rng[slot * 4 + 3]};
-        unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
-        unsigned long long t_prev = 0, r7[6] = {0, 0, 0, 0, 0, 0};      // r7: cycles from barrier B to the relay's way points on this wave
+        unsigned stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+        unsigned t_prev = 0, r7[6] = {0, 0, 0, 0, 0, 0};      // r7: cycles from barrier B to the relay's way points on this wave
         int cur = 0, seq = 0;
         float pred = 0.f, upd_pred = 0.f;
         int upd_exc = 0, upd_i = 0;
@@ -623,7 +625,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             const float *fo = b.frame_out + ((size_t)utt * n_frames + f) * DSS_COND_STRIDE;
             lpc_lane = fo[3 * NA + NB3 + (lane & (DSS_LPC_ORDER - 1))];
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
-                if (STAMP) t_prev = __builtin_readcyclecounter();
+                if (STAMP) t_prev = DSS_NOW();
                 if (!have_spec) {        // first sample of the call: prediction and indices computed directly
                     pred = 0;
 #pragma unroll
@@ -635,9 +637,9 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     if (lane == 0) { L.idx[0] = su; L.idx[1] = pu; L.idx[2] = last_exc; }
                 }
                 ++seq;
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[0] += t - t_prev; t_prev = t; }
+                if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[0] += t - t_prev; t_prev = t; }
                 if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[1] += t - t_prev; t_prev = t; }
+                if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[1] += t - t_prev; t_prev = t; }
                 if (upd_pending) { DSS_S_UPDATE() }                                     // previous sample's bookkeeping
                 {   // off the critical path: this sample's 8 thresholds and GRU B's recurrent half
                     const uint32_t r0 = dss_kiss99_rand(rng);
@@ -663,7 +665,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 for (int j = 0; j < NB; ++j) rec += L.gb_wrec[j * NB3 + row] * L.state_b[j];
                 const float sb_old = L.state_b[lane & (NB - 1)];     // the h lanes' own unit: read here, not after the chain
                 __syncthreads();                                                        // barrier B
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[2] += t - t_prev; t_prev = t; }
+                if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[2] += t - t_prev; t_prev = t; }
                 // While wave 6 runs segment 1, this wave forms the products of segment 2 (weights from L2); while wave 6 sums
                 // segment 3, those of segment 4's first GB4R inputs into the same registers.  Its own part of the chain is sums only.
                 const float *an = L.state_a[cur ^ 1];
@@ -673,19 +675,19 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 f32x4 PQ[GB2 / 4];
                 float acc;
                 DSS_GBG_PREMUL(an + GB1, GB2, GB1 / 4)
-                if (STAMP) r7[0] += __builtin_readcyclecounter() - t_prev;
+                if (STAMP) r7[0] += DSS_NOW() - t_prev;
                 while (__hip_atomic_load(&L.hp_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
                     ;                                    // wave 4's products of this sample are in LDS (it forms them first thing after barrier B);
                                                          //   asked here, where this wave waits for segment 1 anyway
                 DSS_GB_AWAIT(seq * 4 + 1)
-                if (STAMP) r7[1] += __builtin_readcyclecounter() - t_prev;
+                if (STAMP) r7[1] += DSS_NOW() - t_prev;
                 DSS_GB_SUMS(GB2)
                 DSS_GB_PUBLISH(seq * 4 + 2)
-                if (STAMP) { asm volatile("" : "+v"(acc)); r7[2] += __builtin_readcyclecounter() - t_prev; }
+                if (STAMP) { asm volatile("" : "+v"(acc)); r7[2] += DSS_NOW() - t_prev; }
                 DSS_GB_PREMUL(an + (NA - GB4), GB4R, 0, 0)
-                if (STAMP) r7[3] += __builtin_readcyclecounter() - t_prev;
+                if (STAMP) r7[3] += DSS_NOW() - t_prev;
                 DSS_GB_AWAIT(seq * 4 + 3)
-                if (STAMP) r7[4] += __builtin_readcyclecounter() - t_prev;
+                if (STAMP) r7[4] += DSS_NOW() - t_prev;
                 // Segment 4: the first GB4H inputs' sums, then -- their registers being free -- the reads of wave 4's GB4H products,
                 // which land while the remaining GB4R - GB4H products are summed.
                 DSS_GB_SUMS(GB4H)
@@ -701,7 +703,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 DSS_GB_SUMS(GB4H)                                                       // (PQ[0 .. GB4H/4) again: wave 4's products)
-                if (STAMP) { asm volatile("" : "+v"(acc)); r7[5] += __builtin_readcyclecounter() - t_prev; }
+                if (STAMP) { asm volatile("" : "+v"(acc)); r7[5] += DSS_NOW() - t_prev; }
                 {   // gates: lanes 0..15 z, 16..31 r, 32..47 h.  r and z travel up to their unit's h lane with gfx950's
                     // row/half swaps (VALU) instead of ds_bpermute (an LDS round trip each, on the sample's critical
                     // path); the new state is formed in the h lanes.  Only the first result of a swap is used, with
@@ -719,9 +721,9 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 }
 #endif
                 __syncthreads();                                                        // barrier C
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[3] += t - t_prev; t_prev = t; }
+                if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[3] += t - t_prev; t_prev = t; }
                 __syncthreads();                                                        // barrier D
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[4] += t - t_prev; t_prev = t; }
+                if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[4] += t - t_prev; t_prev = t; }
                 cur ^= 1;
                 int val;
                 DSS_TREE_WALK(val)
@@ -735,7 +737,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 upd_exc = exc; upd_pred = pred; upd_i = i; upd_pending = true;       // (all wave-uniform: scalar registers)
                 pred = pred_next;
                 if (i == DSS_FRAME_SIZE - 1) { DSS_S_UPDATE() }
-                if (STAMP) { unsigned long long t = __builtin_readcyclecounter(); stamp_acc[5] += t - t_prev; t_prev = t; }
+                if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[5] += t - t_prev; t_prev = t; }
             }
             // wave 7 owns L.pcm: LDS operations of one wave are ordered, no barrier needed
             for (int k = lane; k < DSS_FRAME_SIZE / 2; k += 64)
