@@ -103,17 +103,30 @@ def _strip_dot_prod(text: str) -> str:
     return _select_branch(text, dot_prod=False)[0]
 
 
-_INT_TOKEN = re.compile(r"^[+-]?(0[xX][0-9a-fA-F]+|\d+)$")
+def _c_int(tok: str) -> int:
+    """A C integer literal as nnet_data.c prints them: hexadecimal with 0x, everything else DECIMAL (a leading zero is
+    padding there, not an octal prefix -- and int(t, 0) refuses '010')."""
+    t = tok.lstrip("+-")
+    v = int(t, 16) if t[:2].lower() == "0x" else int(t, 10)
+    return -v if tok.startswith("-") else v
 
 
-def _parse_resolved(text: str) -> Dict[str, np.ndarray]:
+def _parse_resolved(text: str, dot_prod: bool = False) -> Dict[str, np.ndarray]:
+    """``dot_prod``: which side of the ``#ifdef DOT_PROD`` pairs `text` was resolved to.  It decides the element type of
+    the ``qweight`` arrays (typedef'd to ``float`` in the ``#else`` build, ``signed char`` under DOT_PROD) -- NOT the look of
+    their tokens: a float array whose values all print without a decimal point stays float32."""
     arrays: Dict[str, np.ndarray] = {}
     for ctype, name, body in _ARRAY.findall(text):
         toks = [t for t in re.split(r"[\s,]+", body.strip()) if t]
+        ctype = " ".join(ctype.split())
         if ctype == "int":
-            arrays[name] = np.array([int(t, 0) for t in toks], dtype=np.int32)
-        elif ctype != "float" and toks and all(_INT_TOKEN.match(t) for t in toks):
-            arrays[name] = np.array([int(t, 0) for t in toks], dtype=np.int8)      # qweight / opus_int8 under DOT_PROD
+            arrays[name] = np.array([_c_int(t) for t in toks], dtype=np.int32)
+        elif ctype in ("opus_int8", "signed char") or (ctype == "qweight" and dot_prod):
+            vals = [_c_int(t) for t in toks]
+            bad = [v for v in vals if not -128 <= v <= 127]
+            if bad:
+                raise ValueError(f"{name}: int8 array holds {bad[0]} (outside -128..127)")
+            arrays[name] = np.array(vals, dtype=np.int8)
         else:
             arrays[name] = np.array([float(t.rstrip("fF")) for t in toks], dtype=np.float32)
     return arrays
@@ -140,7 +153,7 @@ def parse_c_arrays_both(text: str):
     fl = _parse_resolved(ftext)
     if not n_blocks:
         return fl, {}, BRANCH_FLOAT
-    dp_all = _parse_resolved(_select_branch(text, dot_prod=True)[0])
+    dp_all = _parse_resolved(_select_branch(text, dot_prod=True)[0], dot_prod=True)
     dp = {k: v for k, v in dp_all.items() if k not in fl or v.dtype != fl[k].dtype or v.size != fl[k].size or not np.array_equal(v, fl[k])}
     return fl, dp, BRANCH_FLOAT | BRANCH_DOT_PROD
 
