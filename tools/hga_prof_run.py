@@ -1,5 +1,5 @@
 """Workload for rocprofv3 over the HGA kernels: 1024 streams x 1.04 s x 64 ch, the plain call and the raw-packet call
-(front end + z-score), each 5 times, through the form DSS_HGA_PATH selects (0 default: fused kernel + separate front end, 3 streamed: one launch)."""
+(front end + z-score), each 5 times, through the form DSS_HGA_PATH selects (0 default: fused kernel + separate front end, 2: three launches)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "delayed-speech-synthesis_amd"))

@@ -1,4 +1,4 @@
-"""Development aid: HGA extractor timing: hga_fused_kernel (default), the three-launch form (DSS_HGA_PATH=2), the streamed one-launch form (=3)."""
+"""Development aid: HGA extractor timing: hga_fused_kernel (default), the three-launch form (DSS_HGA_PATH=2)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "delayed-speech-synthesis_amd"))
@@ -14,8 +14,8 @@ def timeit(fn, n=10):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / n
 
-PATH = int(os.environ.get("DSS_HGA_PATH", "0"))          # 0 default (fused), 2 three launches, 3 streamed (one launch, opt-in)
-tag = {0: "fused", 1: "fused", 2: "3 launches", 3: "streamed"}[PATH]
+PATH = int(os.environ.get("DSS_HGA_PATH", "0"))          # 0 default (fused), 2 three launches
+tag = {0: "fused", 1: "fused", 2: "3 launches"}[PATH]
 for S in (64, 1024):
     x = torch.from_numpy(np.stack([synthetic_ecog(1000 + b % 8, 1040, 64) for b in range(S)])).cuda()
     ex = HgaExtractorGPU(S, 64)
