@@ -360,15 +360,15 @@ def main():
     if extras:
         from dss_amd.models import UnidirectionalVoiceActivityDetector
         from dss_amd.pipeline import GatedStreamingPipeline
-        S, ticks = 128, 375                                          # 15 s of stream time
+        S, ticks = 128, 260                                          # 10 s of stream time behind 10 warm-up ticks
         rng = np.random.default_rng(1)
-        # loud / quiet stretches of 0.2 .. 1 s per stream, and a seeded detector whose two logits mirror each other, so that
+        # loud / quiet stretches of 1 .. 4 s per stream, and a seeded detector whose two logits mirror each other, so that
         # its decision follows the input and both labels occur (no trained checkpoint exists offline)
         env = np.empty((S, ticks * 40))
         for s_ in range(S):
             t_, loud = 0, bool(rng.integers(2))
             while t_ < env.shape[1]:
-                n_ = int(rng.integers(200, 1000))
+                n_ = int(rng.integers(1000, 4000))
                 env[s_, t_:t_ + n_] = 60.0 if loud else 3.0
                 loud, t_ = not loud, t_ + n_
         torch.manual_seed(5)
