@@ -209,3 +209,32 @@ def test_gated_pipeline_with_the_vad_kernel_equals_the_torch_detector():
         for (_, _, x), (_, _, y) in zip(ga, gb):
             assert np.array_equal(x, y)
     assert 0 < n_labels < S * 30 * 4                      # the seeded detector says both things
+
+
+@pytest.mark.parametrize("S,C,H", [(1, 5, 7), (3, 64, 150), (5, 17, 33), (2, 128, 160)])
+def test_vad_kernel_odd_shapes(S, C, H):
+    """Input and hidden sizes that are not multiples of 4 (the kernel's weight copies are padded), stream counts that do not
+    fill the last workgroup, the largest sizes the kernel takes: logits and state against torch.nn.LSTM, float32 and float64
+    frames; sizes beyond the limits are refused, not truncated."""
+    from dss_amd.models import UnidirectionalVoiceActivityDetector
+    from dss_amd.vad import VadLstmGPU, fits
+    torch.manual_seed(100 + H)
+    m = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=H, nb_electrodes=C).eval().cuda()
+    assert fits(m)
+    k = VadLstmGPU(S, m)
+    state = m.create_new_initial_state(batch_size=S, device="cuda")
+    rng = np.random.default_rng(H)
+    for w, dt in ((3, torch.float32), (1, torch.float64), (6, torch.float64)):
+        z = torch.from_numpy(rng.standard_normal((S, w, C))).cuda().to(dt)
+        with torch.no_grad():
+            want, state = m(z.to(torch.float32), state)
+        labels, logits = k.step_torch(z, want_logits=True)
+        assert (logits - want).abs().max().item() <= 2e-5
+        sure = (want[..., 1] - want[..., 0]).abs() > 1e-4
+        assert torch.equal(labels[sure], want.argmax(dim=2).to(torch.int32)[sure])
+    h, c = k.state()
+    assert np.abs(h - state[0].cpu().numpy()).max() <= 2e-5 and np.abs(c - state[1].cpu().numpy()).max() <= 1e-4
+    big = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=512, nb_electrodes=128)      # the class's own defaults
+    assert not fits(big)                                   # beyond the kernel: the pipeline keeps such a model on PyTorch-ROCm
+    three = UnidirectionalVoiceActivityDetector(nb_layer=3, nb_hidden_units=32, nb_electrodes=8)
+    assert not fits(three)
