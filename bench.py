@@ -260,7 +260,7 @@ def main():
         generic = {"kernel": "lpcnet_sample_generic_kernel", "ms_per_step": tg * 1e3, "value": B * FRAMES * FRAME / tg,
                    "unit": "samples/s", "note": "GRU A blocks streamed from L2 every sample: what a model runs on whose sparsity is "
                    "too skewed even for the CU-resident kernel's tail paths (over 16 z/r blocks of a row group beyond its register "
-                   "slots, over 64 h blocks, or an LDS image over 136448 B); dss_lpcnet_model_info reports it, "
+                   "slots, over 64 h blocks, or an LDS image over 151552 B); dss_lpcnet_model_info reports it, "
                    "profiles/r2_model_fit.txt has the steps in between"}
 
     # BASELINE.json configs[3], one GPU's share: 1024 utterances in one call (two utterances per workgroup beyond one per CU)

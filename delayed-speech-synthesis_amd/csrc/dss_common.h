@@ -30,7 +30,7 @@
 #define DSS_ZR_TAIL 16        // max z (and r) blocks per row group beyond its wave's register slots
 #define DSS_HCX 32            // ... in the instantiation with the extended paths (8 VGPRs)
 #define DSS_HX 32             // max h-gate blocks per row group beyond DSS_HCX (column ids from LDS)
-#define DSS_HBLK_BYTES 136448  // dynamic LDS left after the kernel's static 26.7 KB (160 KB per CU)
+#define DSS_HBLK_BYTES 151552  // dynamic LDS left after the kernel's static 11.9 KB (160 KB per CU)
 
 void dss_set_error(const char *fmt, ...);
 

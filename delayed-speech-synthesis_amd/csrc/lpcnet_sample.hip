@@ -10,7 +10,8 @@
 //   GRU A z- and r-gate 8x4 blocks (15k floats)  VGPRs of waves 0..5 (lane = unit; 8 slots per gate on waves 0..3,
 //                                                 all DSS_ZRC on waves 4..5, which get the heaviest row groups)
 //   GRU A h-gate 8x4 blocks (30k floats)          LDS, one 128-byte record per block, grouped per wave
-//   GRU B input weights (18k floats)              VGPRs of waves 6 and 7 (lane = row; 208 + 112 inputs), last 64 in LDS
+//   GRU B input weights (18k floats)              inputs 0..79 and 288..351 in VGPRs of waves 6 and 7 (lane = row); the other 240
+//                                                 stream from L2 every sample into the registers that will hold their products
 //   dual-FC (8k floats)                           VGPRs of waves 0..3 (lane = tree node)
 // Roles inside the 512-thread workgroup (8 waves, 2 per SIMD); three workgroup barriers B C D per sample (a fourth,
 // A, only on the first sample of a call):
@@ -19,10 +20,10 @@
 //               B..C: the h-gate recurrent chain and the z/r block products of the NEXT sample (they need only the
 //               new state) and the speculation over the 256 possible excitations -- hidden under GRU B.
 //               C..D (waves 0..3): dual-FC logits of all 255 tree nodes -> decision bits.
-//   wave 6      GRU B, inputs 0..207: lane = output row, one sequential chain per row, then hands the partial
-//               sums to wave 7 through LDS (flag, no barrier).
-//   wave 7      GRU B inputs 208..383 (the products of the first 48 formed while it waits for wave 6) + gates, and
-//               the scalar recurrences: mu-law / de-emphasis / PCM bookkeeping, kiss99 thresholds, its own tree walk.
+//   wave 6      GRU B, segments 1 and 3 of the chain (see GB1..GB4 below): lane = output row, one sequential chain per row,
+//               handed between the two waves through LDS as a tagged 8-byte word per row (no barrier).
+//   wave 7      GRU B, segments 2 and 4 + gates, and the scalar recurrences: mu-law / de-emphasis / PCM bookkeeping, kiss99
+//               thresholds, its own tree walk.
 // Summation order inside every row is exactly the C source's (one product at a time, ascending input),
 // and the library is built with -ffp-contract=off, so results are bit-identical to the scalar C path.
 #include <cstddef>
@@ -53,29 +54,34 @@
 
 // GRU B: one dependent chain of 384 sums per row.  Four segments that alternate between the two relay waves; every segment
 // but the first is summed from products formed while the other wave was summing (the chain itself is then one v_add_f32
-// per input instead of 1.8 instructions):
-//   segment 1  inputs [0, GB1)            wave 6, multiplied as it goes (nothing can be formed before barrier B)
-//   segment 2  [GB1, GB1+GB2)             wave 7, products formed while wave 6 runs segment 1; weights streamed from L2 into the
-//                                         product registers (slow, but wave 6 needs 1.3 k cycles; no LDS, no extra register)
-//   segment 3  [GB1+GB2, GB1+GB2+GB3)     wave 6, products formed while wave 7 sums segment 2; weights in VGPRs
-//   segment 4  the last GB4 inputs        wave 7.  The window behind segment 2 (wave 6's GB3 sums and two hand-overs) is the
-//                                         shortest of the three and takes GB4R inputs at 6.5 cycles each (weights in VGPRs);
-//                                         the last GB4H inputs are multiplied by WAVE 4 (a GRU A wave with slack; weights in LDS)
-//                                         right after barrier B and come over through LDS.
-// Measured on the way (profiles/r4_relay_experiment.md): rounds 1-3 had two segments (208 + 176 inputs, 48 of them
-// pre-multiplied): 4.06 k cycles from barrier B to C; all of segment 4 on wave 7 stalled the chain by ~400 cycles per sample;
-// "barrier C" as an LDS word polled by the dual-FC waves was slower than the barrier (the polls take issue slots and LDS
-// cycles from the relay waves on the same SIMDs).
+// per input instead of 1.8 instructions).  Only segment 1's weights (and 64 of segment 4's) live in registers: the others
+// come from L2 (m.gb_w_quad, 73 KB, shared by every workgroup) INTO the registers that will hold their products, issued where
+// the wave idles anyway, a sample ahead (DSS_GBG_LOADS), and are multiplied in place once barrier B has released the state:
+//   segment 1  inputs [0, GB1)            wave 6, multiplied as it goes (nothing can be formed before barrier B): ~10.5 cycles/input
+//   segment 2  [GB1, GB1+GB2)             wave 7; weights loaded behind barrier C of the sample before, products while wave 6 runs segment 1
+//   segment 3  [GB1+GB2, GB1+GB2+GB3)     wave 6; weights loaded behind barrier C, products while wave 7 sums segment 2
+//   segment 4  the last GB4 inputs        wave 7; products while wave 6 sums segment 3: the first GB4R with weights in VGPRs, the
+//                                         last GB4H with weights loaded (into the registers segment 2 has left) when segment 2 is summed
+// Sums run at 4.4 cycles per input, in-place products at ~5.5, a hand-over takes 130-150 cycles.
+// Measured on the way (profiles/r4_latency_kernel_experiment.md): rounds 1-3 had two segments (208 + 176 inputs, 48 of them
+// pre-multiplied): 4.06 k cycles from barrier B to C.  The first four-segment form kept 192 + 64 weights in registers and 32 in
+// LDS (multiplied by a GRU A wave): its segment 1 had to be 144 inputs long to cover the L2 loads of segment 2, issued after
+// barrier B.  "Barrier C" as an LDS word polled by the dual-FC waves was slower than the barrier (the polls take issue slots
+// and LDS cycles from the relay waves on the same SIMDs).  One state read ahead is not enough for the in-place products: the
+// LDS answers in 50+ cycles while the six GRU A waves run their h chains, so DSS_GBG_MUL keeps several pairs of reads in flight.
 #ifndef GB1
-#define GB1 144
+#define GB1 80
 #endif
 #ifndef GB2
 #define GB2 96
 #endif
 #ifndef GB3
-#define GB3 48
+#define GB3 112
 #endif
 #define GB4 (NA - GB1 - GB2 - GB3)
+#ifndef DSS_RELAY_STAMP
+#define DSS_RELAY_STAMP 0         // development builds (-DDSS_RELAY_STAMP=1, tools/relay_stamps.py): the relay's way points from the TIMED instantiation
+#endif
 #ifndef DSS_RELAY_MASK
 #define DSS_RELAY_MASK 1
 #endif
@@ -84,17 +90,11 @@
 #endif
 #define GB4R (GB4 - GB4H)
 static_assert(GB4 <= GB2, "segment 4's products reuse segment 2's registers");
-static_assert(GB1 % 16 == 0 && GB2 % 8 == 0 && GB3 % 8 == 0 && GB4R % 8 == 0 && GB4H % 8 == 0 && GB4H >= 8 && GB4H <= GB4R, "segment sizes");
-#define GBL_STRIDE (GB4H + 4)             // stride = 4 mod 8: stride * row mod 64 is one-to-one on row mod 16 (the rows of a 16-lane read group hit distinct banks)
-static_assert((GBL_STRIDE % 8) == 4, "row stride: the 16 rows of a read group on distinct banks");
+static_assert(GB1 % 16 == 0 && GB2 % 8 == 0 && GB3 % 8 == 0 && GB4R % 8 == 0 && GB4H % 8 == 0 && GB4H >= 0 && GB4R > 0, "segment sizes");
 struct SampleLds {
     float state_a[2][NA + 4];             // double-buffered GRU A state; "column 96" of either buffer is four zeros: the
                                           //   input of the h-gate slots a row group does not use (see DSS_H_CHAIN)
     float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
-    float gb_wl[NB3 * GBL_STRIDE];        // GRU B input weights of segment 4's last GB4H inputs, row-major (read by wave 6)
-    float gb_hp[GB4H / 4][64][4];         // ... and their products on the way from wave 4 to wave 7: [quad][lane]
-    int hp_flag;                          // number of the sample gb_hp belongs to
-    int pad0[3];
     float tansig[208];
     float ulaw2lin[256];
     float spec_tab_pred[256];             // speculation over all 256 excitation values (see role A, B..C):
@@ -136,47 +136,41 @@ struct SampleLds {
             __builtin_amdgcn_sched_barrier(0);                                                   \
         }                                                                                        \
     }
-// ... with the weights in LDS (wave 6's share of segment 4): four inputs per trip, [0] state, [1] weights
-#define DSS_GBL_LOAD(T, G)                                                                       \
+// ... with the weights streamed from L2 (segments 2 and 3; m.gb_w_quad: [block of four inputs][lane][4]).  Two halves:
+// DSS_GBG_LOADS issues all N/4 loads INTO the product registers (scalar base + lane offset + immediate per load) -- one sample
+// AHEAD, where the wave idles anyway (wave 7: behind barrier C, while the dual-FC waves work; wave 6: once it has handed
+// segment 3 over), so that neither their issue time (~20 cycles each) nor the L2 latency stands in the relay;
+// DSS_GBG_MUL multiplies every quad in place by its four state values once barrier B has released them.
+#define DSS_GBG_LOADS(N, BLK0) DSS_GBG_LOADS_AT(N, BLK0, 0, gvo)
+#define DSS_GBG_LOADS_AT(N, BLK0, POFF, GVO)                                                     \
     {                                                                                            \
-        T[0] = *reinterpret_cast<const f32x4 *>(al + 4 * (G));                                   \
-        T[1] = *reinterpret_cast<const f32x4 *>(wl + 4 * (G));                                   \
-    }
-// ... with the weights streamed from L2 (segment 2; m.gb_w_quad: [block of four inputs][lane][4]): all N/4 loads are issued
-// up front INTO the product registers -- wave 7 has about 1.3 k idle cycles here and not one register -- and every quad is
-// then multiplied in place by its four state values.  Scalar base + lane offset + immediate per load.
-#define DSS_GBG_PREMUL(AN, N, BLK0)                                                              \
-    {                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < ((N) / 4 + 7) / 8; ++k) asm volatile("" : "+v"(GVO[k]));   /* (not loop-invariant) */ \
         _Pragma("unroll") for (int g = 0; g < (N) / 4; ++g)                                      \
-            PQ[g] = *reinterpret_cast<const f32x4 *>(gq + (size_t)gvo[g >> 3] + (ptrdiff_t)(((BLK0) + g) * 1024 - ((BLK0) + (g & ~7) + 4) * 1024)); \
-        f32x4 xq[2];                                                                             \
-        xq[0] = *reinterpret_cast<const f32x4 *>((AN));                                          \
-        _Pragma("unroll") for (int g = 0; g < (N) / 4; ++g) {                                    \
-            if (g + 1 < (N) / 4) xq[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>((AN) + 4 * (g + 1)); \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-            PQ[g].lo = PQ[g].lo * xq[g & 1].lo;                                                  \
-            PQ[g].hi = PQ[g].hi * xq[g & 1].hi;                                                  \
-            asm volatile("" : "+v"(PQ[g]));                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-        }                                                                                        \
+            PQ[(POFF) + g] = *reinterpret_cast<const f32x4 *>(gq + (size_t)GVO[g >> 3] + (ptrdiff_t)(((BLK0) + g) * 1024 - ((BLK0) + (g & ~7) + 4) * 1024)); \
     }
-// The products of segment 4's last GB4H inputs, formed by a wave that is NOT in the relay (wave 4: the GRU A wave with the most
-// slack between barriers B and C; lane = GRU B row, weights from LDS) and left in LDS for wave 7, with the sample's number
-// behind them.  Neither relay wave has the time (wave 7) or the registers (wave 6: it spilled into segment 1) for them.
-#define DSS_GB_HELPER(AN, SEQ)                                                                   \
+#define DSS_GBG_MUL(AN, N, D) DSS_GBG_MUL_AT(AN, N, D, 0)
+#define DSS_GBG_MUL_AT(AN, N, D, POFF)                                                           \
     {                                                                                            \
-        const int hrow = lane < NB3 ? lane : 0;                                                  \
-        const float *al = (AN) + (NA - GB4H), *wl = L.gb_wl + hrow * GBL_STRIDE;                 \
-        f32x4 tq[2][2];                                                                          \
-        DSS_GBL_LOAD(tq[0], 0)                                                                   \
-        _Pragma("unroll") for (int g = 0; g < GB4H / 4; ++g) {                                   \
-            if (g + 1 < GB4H / 4) DSS_GBL_LOAD(tq[(g + 1) & 1], g + 1)                           \
-            f32x4 hp;                                                                            \
-            hp.lo = tq[g & 1][1].lo * tq[g & 1][0].lo;                                           \
-            hp.hi = tq[g & 1][1].hi * tq[g & 1][0].hi;                                           \
-            *reinterpret_cast<f32x4 *>(&L.gb_hp[g][lane][0]) = hp;                               \
+        /* two quads per trip (one wait, one hazard slot per eight inputs), D - 1 pairs of state reads in flight: with a   \
+           single read ahead every quad waited a full LDS round trip, and the LDS is busy with the h chains here */        \
+        f32x4 xq[D][2];                                                                          \
+        _Pragma("unroll") for (int u = 0; u < (D) - 1; ++u) {                                    \
+            xq[u][0] = *reinterpret_cast<const f32x4 *>((AN) + 8 * u);                           \
+            xq[u][1] = *reinterpret_cast<const f32x4 *>((AN) + 8 * u + 4);                       \
         }                                                                                        \
-        __hip_atomic_store(&L.hp_flag, (SEQ), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   \
+        _Pragma("unroll") for (int g = 0; g < (N) / 8; ++g) {                                    \
+            if (g + (D) - 1 < (N) / 8) {                                                         \
+                xq[(g + (D) - 1) % (D)][0] = *reinterpret_cast<const f32x4 *>((AN) + 8 * (g + (D) - 1));     \
+                xq[(g + (D) - 1) % (D)][1] = *reinterpret_cast<const f32x4 *>((AN) + 8 * (g + (D) - 1) + 4); \
+            }                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            PQ[(POFF) + 2 * g].lo = PQ[(POFF) + 2 * g].lo * xq[g % (D)][0].lo;                   \
+            PQ[(POFF) + 2 * g].hi = PQ[(POFF) + 2 * g].hi * xq[g % (D)][0].hi;                   \
+            PQ[(POFF) + 2 * g + 1].lo = PQ[(POFF) + 2 * g + 1].lo * xq[g % (D)][1].lo;           \
+            PQ[(POFF) + 2 * g + 1].hi = PQ[(POFF) + 2 * g + 1].hi * xq[g % (D)][1].hi;           \
+            asm volatile("" : "+v"(PQ[(POFF) + 2 * g]), "+v"(PQ[(POFF) + 2 * g + 1]));           \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+        }                                                                                        \
     }
 // the sums of a pre-multiplied segment: one dependent chain, input order
 #define DSS_GB_SUMS(N)                                                                           \
@@ -209,6 +203,15 @@ struct SampleLds {
             tag_ = __builtin_bit_cast(unsigned, tf_);                                            \
         } while (__any(tag_ != (unsigned)(V)));                                                  \
         acc = pv_.x;                                                                             \
+    }
+
+// a way point of a relay wave (diagnostic builds): V is pinned on both sides of the clock read, so that what produces V is
+// issued before the stamp and what consumes it after (the clock read is scalar and would otherwise float among the sums)
+#define DSS_RSTAMP(V, SLOT, T0)                                                                  \
+    if (RS) {                                                                                    \
+        asm volatile("" : "+v"(V));                                                              \
+        SLOT += DSS_NOW() - (T0);                                                                \
+        asm volatile("" : "+v"(V));                                                              \
     }
 
 #define DSS_TREE_WALK(VAL) DSS_TREE_WALK_AT(VAL, L.bits)
@@ -255,7 +258,8 @@ struct SampleLds {
 // =====================================================================================================
 template <bool TRACE, bool STAMP, int Z, bool HAS_FC, bool EXT>
 __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const DssModelDev &m, const DssBatchDev &b,
-                                           int n_frames, int utt, int slot, int nf, int fc0, int tid, int wave, int lane)
+                                           int n_frames, int utt, int slot, int nf, int fc0, int tid, int wave, int lane,
+                                           short *pcm_out_dbg)
 {
     constexpr int HC = EXT ? DSS_HCX : DSS_HC;                   // h slots with register-held column ids
     const int unit = m.unit_of[tid];                             // z/r chains + gates of this unit
@@ -403,10 +407,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             }
             __syncthreads();                                                        // barrier B
             if (STAMP) { const unsigned t = DSS_NOW(); sa[4] += t - ta; ta = t; }
-            if constexpr (!HAS_FC) {
-                ++seq;
-                if (wave == 4) DSS_GB_HELPER(L.state_a[cur ^ 1], seq)            // GRU B: wave 7's last products (see DSS_GB_HELPER)
-            }
+            else if (DSS_RELAY_STAMP) ta = DSS_NOW();
             DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
             DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
             if (wave == 5 || wave < 2) {
@@ -426,6 +427,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 L.spec_tab_idx[cand] = (unsigned short)(su_c | (pu_c << 8));
             }
             if (STAMP) { const unsigned t = DSS_NOW(); sa[5] += t - ta; ta = t; }
+            else if (DSS_RELAY_STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); sa[5] += DSS_NOW() - ta; }   // B .. ready for C
             __syncthreads();                                                        // barrier C
             if (STAMP) { const unsigned t = DSS_NOW(); sa[6] += t - ta; ta = t; }
             if constexpr (HAS_FC) {                                                 // sample_mdense, all nodes
@@ -472,6 +474,8 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
     __syncthreads();                                                                // final barrier
     if (STAMP && lane == 0 && b.trace_exc)
         for (int k = 0; k < 8; ++k) b.trace_exc[((size_t)utt * 6 + wave) * 8 + k] = (float)sa[k];
+    if (DSS_RELAY_STAMP && !STAMP && lane == 0 && blockIdx.x == 0)
+        reinterpret_cast<unsigned *>(pcm_out_dbg + (size_t)utt * n_frames * DSS_FRAME_SIZE)[16 + wave] = sa[5];
     b.gru_a_state[(size_t)slot * NA + unit] = st;
 }
 
@@ -487,6 +491,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     static_assert(sizeof(SampleLds) % 16 == 0, "dynamic LDS must start 16-byte aligned");
     static_assert(sizeof(SampleLds) + DSS_HBLK_BYTES <= 160 * 1024, "LDS budget");
     constexpr bool RG = RAGGED || TRACE;
+    constexpr bool RS = STAMP || DSS_RELAY_STAMP;          // way points of the relay waves
     // row of this call (scratch, features, PCM): ragged calls with counts start their longest rows first (b.row_of)
     const int utt = (RG && b.row_of) ? __builtin_amdgcn_readfirstlane(b.row_of[blockIdx.x]) : b.utt0 + (int)blockIdx.x;
     const int slot = (RG && b.slot_of) ? b.slot_of[utt] : utt;                     // decoder state it continues
@@ -499,45 +504,40 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
     for (int k = tid * 4; k < m.hblk_floats; k += 512 * 4)
         *reinterpret_cast<f32x4 *>(&hblk_lds[k]) = *reinterpret_cast<const f32x4 *>(&m.hblk[k]);
     for (int k = tid; k < NB * NB3; k += 512) L.gb_wrec[k] = m.gru_b_w_rec[k];
-    for (int k = tid; k < NB3 * GB4H; k += 512) {
-        const int row = k / GB4H, j = k - row * GB4H;
-        L.gb_wl[row * GBL_STRIDE + j] = m.gb_w_lane[(size_t)(NA - GB4H + j) * 64 + row];
-    }
     if (tid < 201) L.tansig[tid] = m.tansig[tid];
     if (tid < 256) L.ulaw2lin[tid] = m.ulaw2lin[tid];
     if (tid < NA) L.state_a[0][tid] = b.gru_a_state[(size_t)slot * NA + tid];
     if (tid < 8) L.state_a[tid >> 2][NA + (tid & 3)] = 0.f;
     if (tid < NB) L.state_b[tid] = b.gru_b_state[(size_t)slot * NB + tid];
     if (tid < 128) L.gb_acc[tid >> 1][tid & 1] = 0.f;
-    if (tid == 0) L.hp_flag = 0;
     const int fc0 = b.fc0[utt];
     __syncthreads();
 
     if (wave < 4) {
-        dss_role_a<TRACE, STAMP, (Z < 8 ? Z : 8), true, EXT>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane);
+        dss_role_a<TRACE, STAMP, (Z < 8 ? Z : 8), true, EXT>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane, pcm_out);
     } else if (wave < 6) {
-        dss_role_a<TRACE, STAMP, Z, false, EXT>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane);
+        dss_role_a<TRACE, STAMP, Z, false, EXT>(L, hblk_lds, m, b, n_frames, utt, slot, nf, fc0, tid, wave, lane, pcm_out);
     } else if (wave == 6) {
         // =====================================================================================================
-        // role B1: GRU B over inputs 0..207, lane = row (0..15 z, 16..31 r, 32..47 h)
+        // role B1: GRU B, segments 1 and 3; lane = row (0..15 z, 16..31 r, 32..47 h)
         // =====================================================================================================
-        f32x2 WB[(GB1 + GB3) / 2];                   // segment 1's weights, then segment 3's
+        f32x2 WB[GB1 / 2];                           // segment 1's weights; segment 3's come from L2 every sample
 #pragma unroll
         for (int j = 0; j < GB1 / 2; ++j) {
             WB[j].x = m.gb_w_lane[(size_t)(2 * j) * 64 + lane];
             WB[j].y = m.gb_w_lane[(size_t)(2 * j + 1) * 64 + lane];
         }
+        const char *gq = reinterpret_cast<const char *>(m.gb_w_quad);
+        unsigned gvo[(GB3 / 4 + 7) / 8];             // lane offsets of segment 3's eight-block windows in m.gb_w_quad
 #pragma unroll
-        for (int j = 0; j < GB3 / 2; ++j) {
-            WB[GB1 / 2 + j].x = m.gb_w_lane[(size_t)(GB1 + GB2 + 2 * j) * 64 + lane];
-            WB[GB1 / 2 + j].y = m.gb_w_lane[(size_t)(GB1 + GB2 + 2 * j + 1) * 64 + lane];
-        }
+        for (int k = 0; k < (GB3 / 4 + 7) / 8; ++k) gvo[k] = (unsigned)lane * 16 + (unsigned)((GB1 + GB2) / 4 + 8 * k + 4) * 1024u;
+        f32x4 PQ[GB3 / 4];                           // segment 3: weights (loaded a sample ahead), then products
         const unsigned gb_addr = dss_lds_addr(&L.gb_acc[lane][0]);
         const int row = lane < NB3 ? lane : 0;
         __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
         const float gbb0 = m.gru_b_bias[row];
         int cur = 0, seq = 0;
-        unsigned r6[4] = {0, 0, 0, 0};     // diagnostic build: cycles from barrier B to the relay's way points on this wave
+        unsigned r6[5] = {0, 0, 0, 0, 0};     // diagnostic build: cycles from barrier B to the relay's way points on this wave
         __syncthreads();                                             // matches role A's prologue barrier
         for (int f = 0; f < nf; ++f) {
             if (fc0 + f < DSS_FEATURES_DELAY) continue;
@@ -545,30 +545,34 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             for (int i = 0; i < DSS_FRAME_SIZE; ++i) {
                 float acc = gbb0 + gbc;                                                 // compute_gruB
                 ++seq;
-                if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
+                if (seq == 1) {
+                    DSS_GBG_LOADS(GB3, (GB1 + GB2) / 4)                                 // (every later sample: loaded at the end of the one before)
+                    __syncthreads();                                                    // barrier A (first sample only)
+                }
                 __syncthreads();                                                        // barrier B
                 const float *an = L.state_a[cur ^ 1];
                 unsigned t6 = 0;
-                if (STAMP) t6 = DSS_NOW();
+                if (RS) t6 = DSS_NOW();
 #if DSS_RELAY_MASK
                 if (lane < NB3) {        // 48 rows: the other 16 lanes only cost LDS return cycles (every state read is 16 B per ACTIVE lane)
 #endif
                 DSS_GB_CHAIN(an, GB1)                                                   // segment 1, multiplied as it goes
                 DSS_GB_PUBLISH(seq * 4 + 1)
-                if (STAMP) { asm volatile("" : "+v"(acc)); r6[0] += DSS_NOW() - t6; }
-                f32x4 PQ[GB3 / 4];
-                DSS_GB_PREMUL(an + GB1 + GB2, GB3, GB1 / 2, 0)                          // segment 3's products, while wave 7 sums segment 2
-                if (STAMP) r6[1] += DSS_NOW() - t6;
+                DSS_RSTAMP(acc, r6[0], t6)
+                DSS_GBG_MUL(an + GB1 + GB2, GB3, 4)                                        // segment 3's products, while wave 7 sums segment 2
+                DSS_RSTAMP(PQ[GB3 / 4 - 1], r6[1], t6)
                 DSS_GB_AWAIT(seq * 4 + 2)
-                if (STAMP) r6[2] += DSS_NOW() - t6;
+                DSS_RSTAMP(acc, r6[2], t6)
                 DSS_GB_SUMS(GB3)
                 DSS_GB_PUBLISH(seq * 4 + 3)
-                if (STAMP) { asm volatile("" : "+v"(acc)); r6[3] += DSS_NOW() - t6; }
+                DSS_RSTAMP(acc, r6[3], t6)
 #if DSS_RELAY_MASK
                 }
 #endif
                 DSS_SPECULATE(lane)                          // this wave is idle from here to barrier B: candidates 0..63
+                if (RS) r6[4] += DSS_NOW() - t6;
                 __syncthreads();                                                        // barrier C
+                DSS_GBG_LOADS(GB3, (GB1 + GB2) / 4)          // the next sample's segment 3 weights (nothing else to do before barrier B)
                 __syncthreads();                                                        // barrier D
                 cur ^= 1;
             }
@@ -576,9 +580,11 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         __syncthreads();                                                                // final barrier
         if (STAMP && lane == 0 && b.trace_pcm && gridDim.x == 1)
             for (int k = 0; k < 4; ++k) b.trace_pcm[72 + k] = (float)r6[k];
+        if (DSS_RELAY_STAMP && !STAMP && lane == 0 && blockIdx.x == 0)      // development builds only: into the (silent) first frame's PCM
+            for (int k = 0; k < 5; ++k) reinterpret_cast<unsigned *>(pcm_out + (size_t)utt * n_frames * DSS_FRAME_SIZE)[8 + k] = r6[k];
     } else {
         // =====================================================================================================
-        // role B2 + S (wave 7): GRU B inputs 208..383 and gates; scalar recurrences replicated across lanes
+        // role B2 + S (wave 7): GRU B, segments 2 and 4, and gates; scalar recurrences replicated across lanes
         // =====================================================================================================
         f32x2 WB[GB4R / 2];                          // the weights of segment 4's first GB4R inputs
 #pragma unroll
@@ -591,10 +597,11 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         const char *gq = reinterpret_cast<const char *>(m.gb_w_quad);
         unsigned gvo[(GB2 / 4 + 7) / 8];
 #pragma unroll
-        for (int k = 0; k < (GB2 / 4 + 7) / 8; ++k) {
-            gvo[k] = (unsigned)lane * 16 + (unsigned)(GB1 / 4 + 8 * k + 4) * 1024u;
-            asm volatile("" : "+v"(gvo[k]));
-        }
+        for (int k = 0; k < (GB2 / 4 + 7) / 8; ++k) gvo[k] = (unsigned)lane * 16 + (unsigned)(GB1 / 4 + 8 * k + 4) * 1024u;
+        unsigned gvo4[(GB4H / 4 + 7) / 8 + 1];       // ... and of segment 4's last GB4H inputs
+#pragma unroll
+        for (int k = 0; k < (GB4H / 4 + 7) / 8; ++k) gvo4[k] = (unsigned)lane * 16 + (unsigned)((NA - GB4H) / 4 + 8 * k + 4) * 1024u;
+        f32x4 PQ[GB2 / 4];                           // segment 2: weights (loaded a sample ahead), then products; then segment 4's products
         const int row = lane < NB3 ? lane : 0;
         __builtin_amdgcn_s_setprio(3);               // everything this wave does is on the sample's critical path
         const float gbb1 = m.gru_b_bias[NB3 + row];
@@ -605,7 +612,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
         int last_exc = b.last_exc[slot];
         DssKiss99 rng = {b.rng[slot * 4 + 0], b.rng[slot * 4 + 1], b.rng[slot * 4 + 2], b.rng[slot * 4 + 3]};
         unsigned stamp_acc[6] = {0, 0, 0, 0, 0, 0};
-        unsigned t_prev = 0, r7[6] = {0, 0, 0, 0, 0, 0};      // r7: cycles from barrier B to the relay's way points on this wave
+        unsigned t_prev = 0, r7[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // r7: cycles from barrier B to the relay's way points on this wave
         int cur = 0, seq = 0;
         float pred = 0.f, upd_pred = 0.f;
         int upd_exc = 0, upd_i = 0;
@@ -638,7 +645,10 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 }
                 ++seq;
                 if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[0] += t - t_prev; t_prev = t; }
-                if (seq == 1) __syncthreads();                                          // barrier A (first sample only)
+                if (seq == 1) {
+                    DSS_GBG_LOADS(GB2, GB1 / 4)                                         // (every later sample: loaded behind barrier C of the one before)
+                    __syncthreads();                                                    // barrier A (first sample only)
+                }
                 if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[1] += t - t_prev; t_prev = t; }
                 if (upd_pending) { DSS_S_UPDATE() }                                     // previous sample's bookkeeping
                 {   // off the critical path: this sample's 8 thresholds and GRU B's recurrent half
@@ -666,44 +676,29 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 const float sb_old = L.state_b[lane & (NB - 1)];     // the h lanes' own unit: read here, not after the chain
                 __syncthreads();                                                        // barrier B
                 if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[2] += t - t_prev; t_prev = t; }
+                else if (RS) t_prev = DSS_NOW();
                 // While wave 6 runs segment 1, this wave forms the products of segment 2 (weights from L2); while wave 6 sums
                 // segment 3, those of segment 4's first GB4R inputs into the same registers.  Its own part of the chain is sums only.
                 const float *an = L.state_a[cur ^ 1];
 #if DSS_RELAY_MASK
                 if (lane < NB3) {
 #endif
-                f32x4 PQ[GB2 / 4];
                 float acc;
-                DSS_GBG_PREMUL(an + GB1, GB2, GB1 / 4)
-                if (STAMP) r7[0] += DSS_NOW() - t_prev;
-                while (__hip_atomic_load(&L.hp_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq)
-                    ;                                    // wave 4's products of this sample are in LDS (it forms them first thing after barrier B);
-                                                         //   asked here, where this wave waits for segment 1 anyway
+                DSS_GBG_MUL(an + GB1, GB2, 3)
+                DSS_RSTAMP(PQ[GB2 / 4 - 1], r7[0], t_prev)
                 DSS_GB_AWAIT(seq * 4 + 1)
-                if (STAMP) r7[1] += DSS_NOW() - t_prev;
+                DSS_RSTAMP(acc, r7[1], t_prev)
                 DSS_GB_SUMS(GB2)
                 DSS_GB_PUBLISH(seq * 4 + 2)
-                if (STAMP) { asm volatile("" : "+v"(acc)); r7[2] += DSS_NOW() - t_prev; }
-                DSS_GB_PREMUL(an + (NA - GB4), GB4R, 0, 0)
-                if (STAMP) r7[3] += DSS_NOW() - t_prev;
+                DSS_RSTAMP(acc, r7[2], t_prev)
+                DSS_GBG_LOADS_AT(GB4H, (NA - GB4H) / 4, GB4R / 4, gvo4)                 // segment 4: the weights of its last GB4H inputs from L2 into
+                DSS_GB_PREMUL(an + (NA - GB4), GB4R, 0, 0)                              //   the registers segment 2 has left; its first GB4R products
+                DSS_GBG_MUL_AT(an + (NA - GB4H), GB4H, 3, GB4R / 4)                     //   (weights in VGPRs); the last GB4H in place
+                DSS_RSTAMP(PQ[GB4 / 4 - 1], r7[3], t_prev)
                 DSS_GB_AWAIT(seq * 4 + 3)
-                if (STAMP) r7[4] += DSS_NOW() - t_prev;
-                // Segment 4: the first GB4H inputs' sums, then -- their registers being free -- the reads of wave 4's GB4H products,
-                // which land while the remaining GB4R - GB4H products are summed.
-                DSS_GB_SUMS(GB4H)
-#pragma unroll
-                for (int g = 0; g < GB4H / 4; ++g) PQ[g] = *reinterpret_cast<const f32x4 *>(&L.gb_hp[g][lane][0]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = GB4H / 4; q < GB4R / 4; ++q) {
-                    acc += PQ[q].x;
-                    acc += PQ[q].y;
-                    acc += PQ[q].z;
-                    acc += PQ[q].w;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                DSS_GB_SUMS(GB4H)                                                       // (PQ[0 .. GB4H/4) again: wave 4's products)
-                if (STAMP) { asm volatile("" : "+v"(acc)); r7[5] += DSS_NOW() - t_prev; }
+                DSS_RSTAMP(acc, r7[4], t_prev)
+                DSS_GB_SUMS(GB4)
+                DSS_RSTAMP(acc, r7[5], t_prev)
                 {   // gates: lanes 0..15 z, 16..31 r, 32..47 h.  r and z travel up to their unit's h lane with gfx950's
                     // row/half swaps (VALU) instead of ds_bpermute (an LDS round trip each, on the sample's critical
                     // path); the new state is formed in the h lanes.  Only the first result of a swap is used, with
@@ -721,7 +716,9 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 }
 #endif
                 __syncthreads();                                                        // barrier C
+                if (RS) r7[6] += DSS_NOW() - t_prev;
                 if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[3] += t - t_prev; t_prev = t; }
+                DSS_GBG_LOADS(GB2, GB1 / 4)                  // the next sample's segment 2 weights, while the dual-FC waves work
                 __syncthreads();                                                        // barrier D
                 if (STAMP) { const unsigned t = DSS_NOW(); stamp_acc[4] += t - t_prev; t_prev = t; }
                 cur ^= 1;
@@ -748,6 +745,8 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
             for (int k = 0; k < 6; ++k) b.trace_pcm[(size_t)utt * 6 + k] = (float)stamp_acc[k];
             if (gridDim.x == 1) for (int k = 0; k < 6; ++k) b.trace_pcm[64 + k] = (float)r7[k];
         }
+        if (DSS_RELAY_STAMP && !STAMP && lane == 0 && blockIdx.x == 0)
+            for (int k = 0; k < 8; ++k) reinterpret_cast<unsigned *>(pcm_out + (size_t)utt * n_frames * DSS_FRAME_SIZE)[k] = r7[k];
         if (lane < NB) b.gru_b_state[(size_t)slot * NB + lane] = L.state_b[lane];
         if (lane < DSS_LPC_ORDER) b.last_sig[(size_t)slot * DSS_LPC_ORDER + lane] = ls_lane;
         if (lane == 0) {

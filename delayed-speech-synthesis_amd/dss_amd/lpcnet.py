@@ -98,7 +98,7 @@ class LPCNetBatch:
         if not info["fast_path"]:
             import warnings
             warnings.warn("LPCNet model exceeds the CU-resident kernel's capacities (z/r blocks per row group %d of 12+16, "
-                          "h blocks %d of 64, LDS image %d of 138752 B): running on the generic kernel, several times slower"
+                          "h blocks %d of 64, LDS image %d of 151552 B): running on the generic kernel, several times slower"
                           % (info["zr_slots_max"], info["h_slots_max"], info["h_lds_bytes"]), RuntimeWarning, stacklevel=2)
 
     def _check_device(self, t):

@@ -97,7 +97,7 @@ double dss_lpcnet_bytes_per_sample(void);
  *   zr_slots_max  largest z- or r-gate block count of a row group (register slots: 12 on 16 groups, 8 on the other
  *                 32; outer capacity: 16 more per group);
  *   h_slots_max   largest h-gate block count of a row group (28, or 32 in the extended instantiation, with register-held column ids; outer capacity 64);
- *   h_lds_bytes   LDS image: h-gate blocks, z/r tail blocks and their tables (capacity 138 752 B);
+ *   h_lds_bytes   LDS image: h-gate blocks, z/r tail blocks and their tables (capacity 151 552 B);
  *   gru_a_order   dss_blob_header.gru_a_order of the model. */
 int dss_lpcnet_model_info(int *fast_path, int *zr_slots_max, int *h_slots_max, int *h_lds_bytes, int *gru_a_order);
 

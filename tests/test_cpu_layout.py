@@ -40,7 +40,7 @@ def test_layout_reproduces_every_row(seed, skew, fast):
     if fast is not None:
         assert info["fast_path"] == fast, info
     if info["fast_path"]:
-        assert info["lds_bytes"] <= 138752
+        assert info["lds_bytes"] <= 151552                 # DSS_HBLK_BYTES (csrc/dss_common.h)
         # what must sit in LDS at least: every h block, and every z/r block beyond the register slots
         order = np.argsort(-zr, kind="stable")
         caps = np.empty(48, int)
