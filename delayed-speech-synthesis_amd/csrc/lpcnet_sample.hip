@@ -10,7 +10,7 @@
 //   GRU A z- and r-gate 8x4 blocks (15k floats)  VGPRs of waves 0..5 (lane = unit; 8 slots per gate on waves 0..3,
 //                                                 all DSS_ZRC on waves 4..5, which get the heaviest row groups)
 //   GRU A h-gate 8x4 blocks (30k floats)          LDS, one 128-byte record per block, grouped per wave
-//   GRU B input weights (18k floats)              inputs 0..79 and 288..351 in VGPRs of waves 6 and 7 (lane = row); the other 240
+//   GRU B input weights (18k floats)              inputs 0..95 and 288..351 in VGPRs of waves 6 and 7 (lane = row); the other 224
 //                                                 stream from L2 every sample into the registers that will hold their products
 //   dual-FC (8k floats)                           VGPRs of waves 0..3 (lane = tree node)
 // Roles inside the 512-thread workgroup (8 waves, 2 per SIMD); three workgroup barriers B C D per sample (a fourth,
@@ -70,20 +70,29 @@
 // and LDS cycles from the relay waves on the same SIMDs).  One state read ahead is not enough for the in-place products: the
 // LDS answers in 50+ cycles while the six GRU A waves run their h chains, so DSS_GBG_MUL keeps several pairs of reads in flight.
 #ifndef GB1
-#define GB1 80
+#define GB1 96
 #endif
 #ifndef GB2
 #define GB2 96
 #endif
 #ifndef GB3
-#define GB3 112
+#define GB3 96
 #endif
 #define GB4 (NA - GB1 - GB2 - GB3)
+#ifndef DSS_SPEC_WAVE
+#define DSS_SPEC_WAVE 4           // which of waves 4, 5 takes candidates 64..127 of the speculation
+#endif
+#ifndef DSS_D3
+#define DSS_D3 3                  // pairs of state reads in flight (+ 1) while segment 3 / segment 2 is multiplied in place
+#endif                            //   (deeper was slower: 4 / 3 39.8 ms, 6 / 3 39.8, 3 / 2 39.6, 2 / 2 40.0 at 80/96/112/96 inputs)
+#ifndef DSS_D2
+#define DSS_D2 2
+#endif
 #ifndef DSS_RELAY_STAMP
 #define DSS_RELAY_STAMP 0         // development builds (-DDSS_RELAY_STAMP=1, tools/relay_stamps.py): the relay's way points from the TIMED instantiation
 #endif
 #ifndef DSS_RELAY_MASK
-#define DSS_RELAY_MASK 1
+#define DSS_RELAY_MASK 0
 #endif
 #ifndef GB4H
 #define GB4H 32
@@ -299,7 +308,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
         fb0 = m.fc_bias[node]; fb1 = m.fc_bias[DSS_FC_OUT + node];
         ff0 = m.fc_factor[node]; ff1 = m.fc_factor[DSS_FC_OUT + node];
     }
-    const float u2l_c = L.ulaw2lin[(HAS_FC ? 128 + tid : tid - 256) & 255];   // this lane's excitation candidate (waves 0, 1, 4, 5)
+    const float u2l_c = L.ulaw2lin[(HAS_FC ? 128 + tid : tid - 64 * DSS_SPEC_WAVE + 64) & 255];   // this lane's excitation candidate (waves 0, 1, DSS_SPEC_WAVE)
     const int level = 31 - __clz(tid | 1);                       // FC node = (1 << level) | prefix
     const bool recur_first = m.h.gru_a_order == DSS_GRUA_RECUR_FIRST;     // wave-uniform (kernel argument)
     int cur = 0, seq = 0;
@@ -410,13 +419,13 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             else if (DSS_RELAY_STAMP) ta = DSS_NOW();
             DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
             DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
-            if (wave == 5 || wave < 2) {
+            if (wave == DSS_SPEC_WAVE || wave < 2) {
                 // Speculation over all 256 possible excitation values of THIS sample, one candidate per lane of wave 5
                 // (candidates 64..127), of waves 0, 1, which have the lightest B..C load of the dual-FC waves (128..255),
                 // and of wave 6 once it has handed its half of the GRU B chain over (0..63): the next sample's LPC prediction and mu-law indices, so that once the tree walk has
                 // picked the value nobody has to run the two ~40-step dependent chains.  Same expressions, same order
                 // as lpcnet_synthesize_tail_impl().
-                const int cand = HAS_FC ? 128 + tid : tid - 256;
+                const int cand = HAS_FC ? 128 + tid : tid - 64 * DSS_SPEC_WAVE + 64;
                 const float pcm_c = L.spec_pred + u2l_c;
                 float pc = 0;
                 pc -= pcm_c * L.spec_lpc[0];
@@ -559,7 +568,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 DSS_GB_CHAIN(an, GB1)                                                   // segment 1, multiplied as it goes
                 DSS_GB_PUBLISH(seq * 4 + 1)
                 DSS_RSTAMP(acc, r6[0], t6)
-                DSS_GBG_MUL(an + GB1 + GB2, GB3, 4)                                        // segment 3's products, while wave 7 sums segment 2
+                DSS_GBG_MUL(an + GB1 + GB2, GB3, DSS_D3)                                        // segment 3's products, while wave 7 sums segment 2
                 DSS_RSTAMP(PQ[GB3 / 4 - 1], r6[1], t6)
                 DSS_GB_AWAIT(seq * 4 + 2)
                 DSS_RSTAMP(acc, r6[2], t6)
@@ -684,16 +693,19 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 if (lane < NB3) {
 #endif
                 float acc;
-                DSS_GBG_MUL(an + GB1, GB2, 3)
+                DSS_GBG_MUL(an + GB1, GB2, DSS_D2)
                 DSS_RSTAMP(PQ[GB2 / 4 - 1], r7[0], t_prev)
                 DSS_GB_AWAIT(seq * 4 + 1)
                 DSS_RSTAMP(acc, r7[1], t_prev)
                 DSS_GB_SUMS(GB2)
                 DSS_GB_PUBLISH(seq * 4 + 2)
                 DSS_RSTAMP(acc, r7[2], t_prev)
-                DSS_GBG_LOADS_AT(GB4H, (NA - GB4H) / 4, GB4R / 4, gvo4)                 // segment 4: the weights of its last GB4H inputs from L2 into
-                DSS_GB_PREMUL(an + (NA - GB4), GB4R, 0, 0)                              //   the registers segment 2 has left; its first GB4R products
-                DSS_GBG_MUL_AT(an + (NA - GB4H), GB4H, 3, GB4R / 4)                     //   (weights in VGPRs); the last GB4H in place
+                // Segment 4: the weights of its last GB4H inputs from L2 into the registers segment 2 has left (issued BEFORE the
+                // products below: after them was 1.3 % slower); its first GB4R products (weights in VGPRs); the last GB4H in place.
+                DSS_GBG_LOADS_AT(GB4H, (NA - GB4H) / 4, GB4R / 4, gvo4)
+                DSS_GB_PREMUL(an + (NA - GB4), GB4R, 0, 0)
+                DSS_RSTAMP(PQ[GB4R / 4 - 1], r7[7], t_prev)
+                DSS_GBG_MUL_AT(an + (NA - GB4H), GB4H, 3, GB4R / 4)
                 DSS_RSTAMP(PQ[GB4 / 4 - 1], r7[3], t_prev)
                 DSS_GB_AWAIT(seq * 4 + 3)
                 DSS_RSTAMP(acc, r7[4], t_prev)

@@ -35,7 +35,7 @@ def main(path):
     w7, w6, ra = st[:8], st[8:13], st[16:22]
     print(f"{os.path.basename(path)} ({B} rows): wave 6: segment 1 published {w6[0]:.0f}, segment 3 products {w6[1]:.0f}, has the sums {w6[2]:.0f}, "
           f"published {w6[3]:.0f}, speculation done {w6[4]:.0f} | wave 7: segment 2 products {w7[0]:.0f}, has the sums {w7[1]:.0f}, published {w7[2]:.0f}, "
-          f"segment 4 products {w7[3]:.0f}, has the sums {w7[4]:.0f}, summed {w7[5]:.0f}, past barrier C {w7[6]:.0f} | "
+          f"segment 4 first products {w7[7]:.0f}, all {w7[3]:.0f}, has the sums {w7[4]:.0f}, summed {w7[5]:.0f}, past barrier C {w7[6]:.0f} | "
           f"GRU A waves ready for barrier C at " + " ".join(f"{v:.0f}" for v in ra))
 
 
