@@ -376,7 +376,7 @@ def main():
         with torch.no_grad():
             vad.classifier.weight[1] = -vad.classifier.weight[0]
             vad.classifier.bias.zero_()
-        gp = GatedStreamingPipeline(S, 64, channel_means=np.full(64, 5.0), vad=vad, max_segment_frames=400)
+        gp = GatedStreamingPipeline(S, 64, channel_means=np.full(64, 5.0), vad=vad, max_segment_frames=1040)     # no segment can outgrow the 10.4 s of the leg (the seeded detector may hold "speech" across a quiet stretch)
         quiet, closing, n_seg, seg_frames = [], [], 0, 0
         for k in range(ticks):
             pk = rng.standard_normal((S, 40, 64)) * env[:, 40 * k:40 * k + 40, None]
