@@ -1849,3 +1849,92 @@ extern "C" int dss_vad_state(dss_vad *v, float *h, float *c, int set)
     if (c) DSS_HIP_CHECK(set ? hipMemcpy(v->d.c, c, n, hipMemcpyHostToDevice) : hipMemcpy(c, v->d.c, n, hipMemcpyDeviceToHost));
     return DSS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// bidirectional recurrent decoder (Part 6 of include/dss_hip.h; csrc/bilstm_decoder.hip)
+// ------------------------------------------------------------------------------------------------------
+struct dss_dec {
+    int device;
+    DssDecDev d;
+    float *w[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // wT[2][2], b[2][2], wr, br
+    bool loaded = false;
+};
+
+extern "C" dss_dec *dss_dec_create(int max_streams, int max_frames, int n_inputs, int hidden_units, int n_outputs)
+{
+    if (max_streams <= 0 || max_frames <= 0 || n_inputs <= 0 || hidden_units <= 0 || n_outputs <= 0) {
+        dss_set_error("decoder dims must be positive"); return nullptr;
+    }
+    if (ensure_device()) return nullptr;
+    dss_dec *v = new dss_dec;
+    memset(&v->d, 0, sizeof(v->d));
+    v->device = g_device;
+    v->d.S_max = max_streams; v->d.T_max = max_frames; v->d.C = n_inputs; v->d.H = hidden_units; v->d.O = n_outputs;
+    const size_t n = (size_t)max_streams * max_frames * 2 * hidden_units;
+    if (dev_alloc<float>(n, &v->d.mid) || dev_alloc<float>(n, &v->d.top)) {
+        dss_set_error("device allocation failed for the decoder's layer outputs");
+        dss_dec_destroy(v);
+        return nullptr;
+    }
+    return v;
+}
+
+extern "C" void dss_dec_destroy(dss_dec *v)
+{
+    if (!v) return;
+    hipSetDevice(v->device);
+    for (float *p : v->w) if (p) hipFree(p);
+    if (v->d.mid) hipFree(v->d.mid);
+    if (v->d.top) hipFree(v->d.top);
+    delete v;
+}
+
+// w: 18 host arrays in torch.nn.LSTM's own layout, in state_dict order of the reference class:
+//   for layer in (0, 1): for direction in (forward, reverse): weight_ih [4H][Cin], weight_hh [4H][H], bias_ih [4H], bias_hh [4H]
+//   (Cin = n_inputs for layer 0, 2H for layer 1), then regressor.weight [O][2H], regressor.bias [O]
+extern "C" int dss_dec_load_weights(dss_dec *v, const float *const *w)
+{
+    if (!v || !w) { dss_set_error("dss_dec_load_weights: null argument"); return DSS_EINVAL; }
+    for (int k = 0; k < 18; ++k) if (!w[k]) { dss_set_error("dss_dec_load_weights: null array %d", k); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(v->device));
+    const int H = v->d.H, H4 = 4 * H, Hp = (H + 3) & ~3;
+    for (float *&p : v->w) { if (p) hipFree(p); p = nullptr; }
+    int rc = 0;
+    for (int layer = 0; layer < 2; ++layer) {
+        const int Cin = layer ? 2 * H : v->d.C, Cp = (Cin + 3) & ~3;
+        for (int dir = 0; dir < 2; ++dir) {
+            const float *w_ih = w[(layer * 2 + dir) * 4 + 0], *w_hh = w[(layer * 2 + dir) * 4 + 1];
+            const float *b_ih = w[(layer * 2 + dir) * 4 + 2], *b_hh = w[(layer * 2 + dir) * 4 + 3];
+            // the kernel's copy: [inputs / 4][4H rows][4 consecutive inputs], input counts padded to multiples of 4 with zero weights
+            std::vector<float> t((size_t)(Cp + Hp) * H4, 0.f), b(H4);
+            auto put = [&](int k, int r, float x) { t[((size_t)(k >> 2) * H4 + r) * 4 + (k & 3)] = x; };
+            for (int r = 0; r < H4; ++r) {
+                for (int k = 0; k < Cin; ++k) put(k, r, w_ih[(size_t)r * Cin + k]);
+                for (int k = 0; k < H; ++k) put(Cp + k, r, w_hh[(size_t)r * H + k]);
+                b[r] = b_ih[r] + b_hh[r];
+            }
+            rc |= dev_upload<float>(t.data(), t.size(), &v->w[layer * 2 + dir]);
+            rc |= dev_upload<float>(b.data(), b.size(), &v->w[4 + layer * 2 + dir]);
+            v->d.wT[layer][dir] = v->w[layer * 2 + dir];
+            v->d.b[layer][dir] = v->w[4 + layer * 2 + dir];
+        }
+    }
+    rc |= dev_upload<float>(w[16], (size_t)v->d.O * 2 * H, &v->w[8]);
+    rc |= dev_upload<float>(w[17], (size_t)v->d.O, &v->w[9]);
+    if (rc) return DSS_ENOMEM;
+    v->d.wr = v->w[8]; v->d.br = v->w[9];
+    v->loaded = true;
+    return DSS_OK;
+}
+
+// d_frames: (n_streams, n_frames, n_inputs) float64 (frames_are_f64: as the extractor returns them; cast to float32 like
+// units.py:503) or float32; d_feats: (n_streams, n_frames, n_outputs) float32.  Device pointers; asynchronous on hip_stream.
+// Every call starts from the zero state (units.py:499-508: a fresh state per segment).
+extern "C" int dss_dec_forward_dev(dss_dec *v, const void *d_frames, int frames_are_f64, int n_streams, int n_frames, float *d_feats,
+                                   void *hip_stream)
+{
+    if (!v || !d_frames || !d_feats) { dss_set_error("dss_dec_forward_dev: bad arguments"); return DSS_EINVAL; }
+    if (!v->loaded) { dss_set_error("dss_dec_forward_dev: no weights loaded (dss_dec_load_weights)"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(v->device));
+    return dss_launch_decoder(v->d, d_frames, frames_are_f64, n_streams, n_frames, d_feats, (hipStream_t)hip_stream);
+}

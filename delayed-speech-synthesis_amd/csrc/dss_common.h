@@ -181,6 +181,17 @@ struct DssVadDev {
 };
 int dss_launch_vad(const DssVadDev &v, const void *d_frames, int frames_f64, int W, int *d_labels, float *d_logits, hipStream_t s);
 
+// ---- bidirectional recurrent decoder (bilstm_decoder.hip) ----------------------------------------------------
+struct DssDecDev {
+    int S_max, T_max, C, H, O;    // capacity (streams x frames per call), inputs per frame, hidden units per direction, outputs (20)
+    const float *wT[2][2];        // [layer][direction]: [(Cin_p + Hp) / 4][4H][4]: weight_ih then weight_hh, four consecutive inputs of
+                                  //   a row side by side, input counts padded to multiples of 4 (Cin = C, then 2H; gate order i, f, g, o)
+    const float *b[2][2];         // [4H]  bias_ih + bias_hh
+    const float *wr, *br;         // regressor [O][2H], [O]
+    float *mid, *top;             // [S_max][T_max][2H] each: the outputs of layer 0 / layer 1 (forward | backward)
+};
+int dss_launch_decoder(const DssDecDev &d, const void *d_frames, int frames_f64, int S, int T, float *d_feats, hipStream_t s);
+
 struct DssHgaDev {
     int S, C, fs, nsec;
     float wl, ws;

@@ -74,6 +74,10 @@ def _declare(L):
         "dss_vad_reset": (i, [vp, i]),
         "dss_vad_step_dev": (i, [vp, vp, i, i, vp, vp, vp]),
         "dss_vad_state": (i, [vp, vp, vp, i]),
+        "dss_dec_create": (vp, [i, i, i, i, i]),
+        "dss_dec_destroy": (None, [vp]),
+        "dss_dec_load_weights": (i, [vp, vp]),
+        "dss_dec_forward_dev": (i, [vp, vp, i, i, i, vp, vp]),
         "dss_hga_num_windows": (i, [i, i, f, f]),
         "dss_hga_log_power": (i, [vp, i, i, i, f, f, vp]),
         "dss_hga_create": (vp, [i, i, i, f, f, i, vp, vp, vp, vp]),

@@ -12,7 +12,7 @@ import subprocess
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_PATH = os.path.join(PKG_ROOT, "libdss_hip.so")
-SOURCES = ["dss_capi.cpp", "hga_kernels.hip", "lpcnet_frame.hip", "lpcnet_sample.hip", "lpcnet_sample_pair.hip", "lpcnet_sample_generic.hip", "speech_gate.hip", "vad_lstm.hip"]
+SOURCES = ["dss_capi.cpp", "hga_kernels.hip", "lpcnet_frame.hip", "lpcnet_sample.hip", "lpcnet_sample_pair.hip", "lpcnet_sample_generic.hip", "speech_gate.hip", "vad_lstm.hip", "bilstm_decoder.hip"]
 HEADERS = ["dss_common.h", "lpcnet_device.h", "lpcnet_sample_common.h", "../../include/dss_hip.h", "../../include/dss_lpcnet_blob.h"]
 # -ffp-contract=off: the path's parity contract is "same products, same sums, same order" as the scalar C
 # reference; a fused multiply-add anywhere would change results.

@@ -35,16 +35,31 @@ class _DecoderMixin:
             decoder = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=n_channels)
         return decoder.eval().cuda()
 
+    def _make_decoder_kernel(self, max_streams, max_frames, use_kernel=True):
+        """The reference's decoder (2-layer bidirectional LSTM + linear head, models.py:36-58) runs in three launches on the
+        library's own kernels (dss_dec_forward_dev: all streams, all frames of the call, zero initial state); any other module
+        is called as given, on PyTorch-ROCm."""
+        from . import decoder as _dec
+        self.dec_gpu = _dec.BiLstmDecoderGPU(max_streams, max_frames, self.decoder) if (use_kernel and _dec.fits(self.decoder)) else None
+
+    def _decode(self, x):
+        """x: CUDA (B, T, C) float64 or float32 -> float32 (B, T, 20), from a fresh zero state (units.py:499-508)."""
+        if self.dec_gpu is not None and x.shape[0] <= self.dec_gpu.S and x.shape[1] <= self.dec_gpu.T:
+            return self.dec_gpu(x)
+        feats, _ = self.decoder(x.to(torch.float32), self.decoder.create_new_initial_state(batch_size=x.shape[0], device="cuda"))
+        return feats.contiguous()
+
 
 class SegmentPipeline(_DecoderMixin):
     def __init__(self, batch: int, n_samples: int = 1040, n_channels: int = 64, fs: int = 1000,
                  channel_means: Optional[np.ndarray] = None, channel_stds: Optional[np.ndarray] = None,
                  decoder: Optional[torch.nn.Module] = None, seed: int = 0, window_length: float = 0.05,
-                 window_shift: float = 0.01):
+                 window_shift: float = 0.01, use_decoder_kernel: bool = True):
         self.B, self.n, self.C = batch, n_samples, n_channels
         self.hga = HgaExtractorGPU(batch, n_channels, fs=fs, window_length=window_length, window_shift=window_shift)
         self.frames = self.hga.frames_for(n_samples)
         self.decoder = self._make_decoder(n_channels, decoder, seed)
+        self._make_decoder_kernel(batch, self.frames, use_decoder_kernel)
         self.vocoder = LPCNetBatch(batch, self.frames)
         mean = np.zeros(n_channels) if channel_means is None else np.asarray(channel_means, dtype=np.float64)
         std = np.ones(n_channels) if channel_stds is None else np.asarray(channel_stds, dtype=np.float64)
@@ -68,28 +83,31 @@ class SegmentPipeline(_DecoderMixin):
                 self.hga.set_zscore(*self._zs)
                 self._zs_on = True
             hga = None
-            z = self.hga.extract_torch(ecog, apply_log=True).to(torch.float32)    # z-scored frames straight from the launch
+            z = self.hga.extract_torch(ecog, apply_log=True)                      # z-scored frames straight from the launch
         else:                                                                 # (test tap: the frames before the z-score)
             if self._zs_on:
                 self.hga.set_zscore(None)
                 self._zs_on = False
             hga = self.hga.extract_torch(ecog, apply_log=True)                # (B, W, C) float64
-            z = ((hga - self.mean) / self.std).to(torch.float32)              # ZScoreNormalization, then .float()
-        feats, _ = self.decoder(z, self.decoder.create_new_initial_state(batch_size=self.B, device="cuda"))
-        pcm = self.vocoder.synthesize_torch(feats.contiguous())
+            z = (hga - self.mean) / self.std                                  # ZScoreNormalization (.float() in the decoder call)
+        feats = self._decode(z)
+        pcm = self.vocoder.synthesize_torch(feats)
         return (pcm, hga, feats) if return_intermediates else pcm
 
 
 class StreamingPipeline(_DecoderMixin):
     def __init__(self, n_streams: int, n_channels: int = 64, fs: int = 1000, packet: int = 40,
-                 decoder: Optional[torch.nn.Module] = None, seed: int = 0, use_graph: bool = True):
+                 decoder: Optional[torch.nn.Module] = None, seed: int = 0, use_graph: bool = True,
+                 use_decoder_kernel: bool = True):
         self.S, self.C, self.packet = n_streams, n_channels, packet
         self.hga = HgaExtractorGPU(n_streams, n_channels, fs=fs)
         self.decoder = self._make_decoder(n_channels, decoder, seed)
+        self._make_decoder_kernel(n_streams, 8, use_decoder_kernel)
         self.vocoder = LPCNetBatch(n_streams, 8)
         self._in = torch.empty((n_streams, packet, n_channels), dtype=torch.float64, device="cuda")
-        # The steady-state tick (every packet after the first: 4 frames) is a fixed sequence of ~25 small launches: HGA,
-        # the MIOpen LSTM's kernels, the frame-rate network, the sample-rate kernel.  It is captured once into a HIP graph and
+        # The steady-state tick (every packet after the first: 4 frames) is a fixed sequence of small launches: HGA, the decoder
+        # (three launches of the library's own kernels; ~20 of MIOpen's for a module of another architecture), the frame-rate
+        # network, the sample-rate kernel.  It is captured once into a HIP graph and
         # replayed per packet, which takes the per-launch host cost off the latency path.  Same kernels, same results.
         self.use_graph = use_graph
         self._graph = None
@@ -102,8 +120,7 @@ class StreamingPipeline(_DecoderMixin):
     @torch.no_grad()
     def _tick(self):
         hga = self.hga.extract_torch(self._in, apply_log=True)
-        feats, _ = self.decoder(hga.to(torch.float32), self.decoder.create_new_initial_state(batch_size=self.S, device="cuda"))
-        feats = feats.contiguous()
+        feats = self._decode(hga)
         self.last_hga, self.last_feats = hga, feats
         return self.vocoder.synthesize_torch(feats)
 
@@ -162,10 +179,11 @@ class GatedStreamingPipeline(_DecoderMixin):
                  buffer_size: int = 2000, context_frames: int = 50, smoothing_context: int = 5,
                  channel_means: Optional[np.ndarray] = None, channel_stds: Optional[np.ndarray] = None,
                  decoder: Optional[torch.nn.Module] = None, vad: Optional[torch.nn.Module] = None, seed: int = 0,
-                 max_segment_frames: Optional[int] = None, use_vad_kernel: bool = True):
+                 max_segment_frames: Optional[int] = None, use_vad_kernel: bool = True, use_decoder_kernel: bool = True):
         self.S, self.C, self.packet = n_streams, n_channels, packet
         self.hga = HgaExtractorGPU(n_streams, n_channels, fs=fs)
         self.decoder = self._make_decoder(n_channels, decoder, seed)
+        self._make_decoder_kernel(1, int(max_segment_frames or buffer_size), use_decoder_kernel)
         if vad is None:
             from .models import UnidirectionalVoiceActivityDetector
             torch.manual_seed(seed + 1)     # no trained checkpoint exists offline: seeded random weights
@@ -225,8 +243,7 @@ class GatedStreamingPipeline(_DecoderMixin):
                 if counts[k] == 0:
                     continue
                 seg = self.gate.segment_torch(s, e)
-                y, _ = self.decoder(seg[None], self.decoder.create_new_initial_state(batch_size=1, device="cuda"))
-                feats[k, :counts[k]] = y[0]
+                feats[k, :counts[k]] = self._decode(seg[None])[0]
             pcm = self.vocoder.synthesize_ragged_torch(feats, counts, slots=streams).cpu().numpy()
             for k, s in enumerate(streams):
                 previous = self.frame_counter - counts[k] - (W - int(events[s, 1]))    # units.py:445

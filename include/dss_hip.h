@@ -290,6 +290,30 @@ int dss_vad_step_dev(dss_vad *v, const void *d_frames, int frames_are_f64, int n
 /* Host copies of the recurrent state, [2 layers][n_streams][H] each, either may be NULL; set == 0 reads, else writes. */
 int dss_vad_state(dss_vad *v, float *h, float *c, int set);
 
+/* ------------------------------------------------------------------------------------------------
+ * Part 6 -- the bidirectional recurrent decoder between the extractor and the vocoder:
+ * BidirectionalSpeechSynthesisModel (local/models.py:36-58: LSTM(n_inputs -> H, 2 layers, bidirectional) ->
+ * Linear(2H -> 20)) as DecodingModel.process calls it (local/units.py:499-508): all frames of a segment (or of a
+ * packet, in the chunk-wise streaming mode), zero initial state per call, frames cast to float32.  Three launches per
+ * call (csrc/bilstm_decoder.hip: one per layer with both directions side by side, one for the regressor) instead of
+ * MIOpen's chain of ~20.  The reference's arithmetic here is torch.nn.LSTM's: results agree with it to ~1e-6 on the
+ * features (tested at 2e-5 against the reference-generated golden vector), not bit for bit.  A decoder of another
+ * architecture stays a PyTorch-ROCm module (dss_amd/pipeline.py falls back to it).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dss_dec dss_dec;
+dss_dec *dss_dec_create(int max_streams, int max_frames, int n_inputs /* <= 256 */, int hidden_units /* <= 128 */, int n_outputs);
+void dss_dec_destroy(dss_dec *v);
+/* w: 18 host arrays in torch.nn.LSTM's own layout (state_dict of the reference class, gate order i, f, g, o):
+ * for layer l in (0, 1), for (forward, reverse): lstm.weight_ih_l{l}[_reverse] [4H][Cin], lstm.weight_hh_l{l}[_reverse] [4H][H],
+ * lstm.bias_ih_l{l}[_reverse] [4H], lstm.bias_hh_l{l}[_reverse] [4H] (Cin = n_inputs for l = 0, 2H for l = 1); then
+ * regressor.weight [n_outputs][2H], regressor.bias [n_outputs]. */
+int dss_dec_load_weights(dss_dec *v, const float *const *w);
+/* Device pointers, enqueued on hip_stream: d_frames (n_streams, n_frames, n_inputs) float64 (frames_are_f64 != 0: as
+ * dss_hga_extract_dev returns them) or float32; d_feats (n_streams, n_frames, n_outputs) float32 -- what
+ * dss_lpcnet_batch_synthesize_dev takes. */
+int dss_dec_forward_dev(dss_dec *v, const void *d_frames, int frames_are_f64, int n_streams, int n_frames, float *d_feats,
+                        void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""GPU tests of the bidirectional decoder kernels (csrc/bilstm_decoder.hip) through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(C=64, H=100, seed=0):
+    from dss_amd.models import BidirectionalSpeechSynthesisModel
+    torch.manual_seed(seed)
+    return BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=H, nb_electrodes=C).eval()
+
+
+def test_decoder_kernel_matches_the_reference_golden_and_torch(golden):
+    """The three-launch BiLSTM against the reference's own decoder: the golden features /root/reference's
+    BidirectionalSpeechSynthesisModel produced on the CPU (oracle/make_golden.py: torch.manual_seed(0), one segment of 100
+    frames, zero state) within 2e-5 -- the tolerance the PyTorch-ROCm module itself is tested at -- for float32 and float64
+    frames; and, for 128 streams x 4 frames (the streaming tick) and 64 x 100 (config 3), torch.nn.LSTM running the same
+    weights on the GPU."""
+    from dss_amd.decoder import BiLstmDecoderGPU, fits
+    g = golden("models.npz")
+    m = _model()
+    assert fits(m) and sum(p.numel() for p in m.parameters()) == int(g["bilstm_params"][0])
+    x = torch.from_numpy(g["bilstm_in"]).cuda()            # (1, 100, 64) float32
+    k = BiLstmDecoderGPU(4, 128, m)
+    y32 = k(x).cpu().numpy()
+    y64 = k(x.to(torch.float64)).cpu().numpy()            # the float64 entry casts like units.py:503
+    assert y32.shape == (1, 100, 20) and np.array_equal(y32, y64)
+    assert np.abs(y32 - g["bilstm_out"]).max() <= 2e-5
+    mg = m.cuda()
+    rng = np.random.default_rng(4)
+    for S, T in ((128, 4), (64, 100), (5, 1)):
+        k = BiLstmDecoderGPU(S, T, mg)
+        z = torch.from_numpy(rng.standard_normal((S, T, 64)) * 2.0).cuda()
+        with torch.no_grad():
+            want, _ = mg(z.to(torch.float32), mg.create_new_initial_state(batch_size=S, device="cuda"))
+        got = k(z)
+        assert got.shape == want.shape and (got - want).abs().max().item() <= 2e-5
+        # every call starts from the zero state: the same input gives the same output again
+        assert torch.equal(k(z), got)
+        # fewer streams / frames than the handle was built for
+        if S > 2 and T > 2:
+            part = k(z[:S - 1, :T - 1])
+            with torch.no_grad():
+                wp, _ = mg(z[:S - 1, :T - 1].to(torch.float32), mg.create_new_initial_state(batch_size=S - 1, device="cuda"))
+            assert (part - wp).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("S,T,C,H", [(1, 3, 5, 7), (3, 6, 64, 100), (6, 2, 17, 33), (2, 5, 256, 128)])
+def test_decoder_kernel_odd_shapes(S, T, C, H):
+    """Input and hidden sizes that are not multiples of 4 (the kernel's weight copies are padded), stream counts that do not
+    fill the last workgroup, the largest sizes the kernel takes; sizes and architectures beyond it are refused, not truncated."""
+    from dss_amd.decoder import BiLstmDecoderGPU, fits
+    from dss_amd.models import BidirectionalSpeechSynthesisModel, UnidirectionalVoiceActivityDetector
+    m = _model(C, H, seed=200 + H).cuda()
+    assert fits(m)
+    k = BiLstmDecoderGPU(S, T, m)
+    rng = np.random.default_rng(H)
+    for dt in (torch.float32, torch.float64):
+        z = torch.from_numpy(rng.standard_normal((S, T, C))).cuda().to(dt)
+        with torch.no_grad():
+            want, _ = m(z.to(torch.float32), m.create_new_initial_state(batch_size=S, device="cuda"))
+        assert (k(z) - want).abs().max().item() <= 2e-5
+    with pytest.raises(ValueError):
+        k(torch.zeros((S + 1, T, C), device="cuda"))
+    with pytest.raises(ValueError):
+        k(torch.zeros((S, T + 1, C), device="cuda"))
+    assert not fits(BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=256, nb_electrodes=64))
+    assert not fits(BidirectionalSpeechSynthesisModel(nb_layer=3, nb_hidden_units=32, nb_electrodes=8))
+    assert not fits(UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=32, nb_electrodes=8))
+
+
+def test_pipelines_with_the_decoder_kernel_agree_with_the_torch_decoder():
+    """SegmentPipeline and StreamingPipeline with the reference's decoder: the kernel path (default) and the PyTorch-ROCm
+    module give features within 2e-5 of each other on the same input, and each path's PCM is what the vocoder makes of ITS
+    features (the vocoder is bit-exact per feature vector, tests/test_gpu_units.py)."""
+    from dss_amd.lpcnet import load_model
+    from dss_amd.lpcnet_weights import synthetic_blob
+    from dss_amd.pipeline import SegmentPipeline, StreamingPipeline
+    from dss_amd.synthetic import synthetic_ecog
+    load_model(synthetic_blob(0))
+    B = 4
+    x = torch.from_numpy(np.stack([synthetic_ecog(70 + b, 1040, 64) for b in range(B)])).cuda()
+    a = SegmentPipeline(B, 1040, 64, channel_means=np.full(64, 4.0), channel_stds=np.full(64, 1.5), seed=2)
+    b = SegmentPipeline(B, 1040, 64, channel_means=np.full(64, 4.0), channel_stds=np.full(64, 1.5), seed=2, use_decoder_kernel=False)
+    assert a.dec_gpu is not None and b.dec_gpu is None
+    pa, _, fa = a(x, return_intermediates=True)
+    pb, _, fb = b(x, return_intermediates=True)
+    assert fa.shape == fb.shape and (fa - fb).abs().max().item() <= 2e-5
+    assert pa.shape == pb.shape and pa.dtype == torch.int16
+    # the streaming tick, eager and graph-replayed, against the module on the same frames
+    S = 8
+    sk = StreamingPipeline(S, 64, seed=2)
+    sm = StreamingPipeline(S, 64, seed=2, use_decoder_kernel=False)
+    assert sk.dec_gpu is not None and sm.dec_gpu is None
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        pk = rng.standard_normal((S, 40, 64)) * 50.0
+        ya, yb = sk.push(pk), sm.push(pk)
+        assert ya.shape == yb.shape
+        assert torch.equal(sk.last_hga, sm.last_hga)
+        assert (sk.last_feats - sm.last_feats).abs().max().item() <= 2e-5
