@@ -333,7 +333,7 @@ def main():
         torch.cuda.synchronize()
         t3 = (time.perf_counter() - t3) / 3
         config3 = {"workload": "configs[2]: 64 segments x 1.04 s x 64-ch synthetic ECoG @1 kHz -> HGA (fused kernel) -> z-score -> "
-                               "BiLSTM (PyTorch-ROCm, seeded weights) -> LPCNet -> int16 PCM, fresh extractor and decoder per segment",
+                               "BiLSTM (csrc/bilstm_decoder.hip: three launches; seeded weights) -> LPCNet -> int16 PCM, fresh extractor and decoder per segment",
                    "ms_per_step": t3 * 1e3, "audio_seconds": float(pcm3.shape[0] * pcm3.shape[1] / 16000.0),
                    "x_realtime": float(pcm3.shape[0] * pcm3.shape[1] / 16000.0 / t3),
                    "note": "64 workgroups on 256 CUs: bounded by the single-utterance speed of the sample-rate kernel, not by HGA or the BiLSTM"}
@@ -349,7 +349,7 @@ def main():
         latency = {"p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
                    "ticks": int(args.latency_ticks), "stream_seconds": args.latency_ticks * 0.04,
                    "config": "128 concurrent 64-ch ECoG streams, one 40-sample packet per stream per tick (4 frames): host "
-                             "packet in -> HGA -> BiLSTM (chunk-wise, VAD gating off) -> LPCNet -> 640 int16 samples per "
+                             "packet in -> HGA -> BiLSTM (csrc/bilstm_decoder.hip, chunk-wise, VAD gating off) -> LPCNet -> 640 int16 samples per "
                              "stream back on the host (steady-state tick replayed from a captured HIP graph); structural floor of the reference (0.55 s + whole-segment "
                              "synthesis) not included"}
 

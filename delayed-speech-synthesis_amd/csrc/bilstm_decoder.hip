@@ -21,6 +21,9 @@
 #define DEC_THREADS 512           // >= 4 * H and >= DEC_SPW * H
 #define DEC_MAXH 128              // (a multiple of 4)
 #define DEC_MAXC 256              // inputs of a layer: n_inputs for layer 0, 2H above it
+#ifndef DEC_INFLIGHT
+#define DEC_INFLIGHT 8
+#endif
 
 typedef float df4 __attribute__((ext_vector_type(4)));
 
@@ -32,12 +35,12 @@ __device__ __forceinline__ void dec_dot(df4 &acc, const float *__restrict__ wq, 
 {
     const df4 *wr = reinterpret_cast<const df4 *>(wq) + row;
     int q = 0;
-    for (; q + 4 <= n / 4; q += 4) {                       // four 16-byte loads in flight
-        df4 w[4];
+    for (; q + DEC_INFLIGHT <= n / 4; q += DEC_INFLIGHT) { // DEC_INFLIGHT 16-byte loads in flight (L2 latency bounds a step)
+        df4 w[DEC_INFLIGHT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = wr[(size_t)(q + u) * H4];
+        for (int u = 0; u < DEC_INFLIGHT; ++u) w[u] = wr[(size_t)(q + u) * H4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < DEC_INFLIGHT; ++u) {
             const df4 x0 = x[4 * (q + u)], x1 = x[4 * (q + u) + 1], x2 = x[4 * (q + u) + 2], x3 = x[4 * (q + u) + 3];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
