@@ -115,9 +115,11 @@ def test_gated_streaming_pipeline_against_per_stream_composition(oracle):
         for s in range(S):
             segs, n_sp = host[s].push(z[s], labels[s])
             for seg in segs:
-                with torch.no_grad():
-                    y, _ = pipe.decoder(torch.from_numpy(seg)[None].cuda(),
-                                        pipe.decoder.create_new_initial_state(batch_size=1, device="cuda"))
+                x = torch.from_numpy(seg)[None].cuda()
+                y = pipe._decode(x)                      # the decoder as the pipeline runs it (csrc/bilstm_decoder.hip) ...
+                with torch.no_grad():                    # ... which agrees with the PyTorch-ROCm module on the same weights
+                    yt, _ = pipe.decoder(x, pipe.decoder.create_new_initial_state(batch_size=1, device="cuda"))
+                assert pipe.dec_gpu is not None and (y - yt).abs().max().item() <= 2e-5
                 feats = y[0].cpu().numpy()
                 pcm = np.concatenate([vocoders[s].synthesize(feats[t]) for t in range(len(feats))])
                 want.append((s, counter - len(seg) - (W - n_sp), pcm))
