@@ -166,3 +166,21 @@ def test_runner_swaps_the_gpu_units_into_an_unchanged_user_script(tmp_path):
     assert os.path.join("delayed-speech-synthesis_amd", "LPCNet.py") in out.stdout
     assert "local.units.HighGammaExtractor: replaced" in out.stderr
     assert "local.training.AsynchronousSynthesisQueue: left alone" in out.stderr      # this user tree has no training.py
+
+
+def test_kernel_fit_checks_of_the_recurrent_models():
+    """Which modules the library's own LSTM kernels take over (host-side check, no GPU): exactly the reference's two
+    architectures within the kernels' sizes; anything else stays a PyTorch-ROCm module."""
+    from dss_amd import decoder, vad
+    from dss_amd.models import BidirectionalSpeechSynthesisModel, UnidirectionalVoiceActivityDetector
+    dec = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64)
+    det = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64)
+    assert decoder.fits(dec) and vad.fits(det)
+    assert not decoder.fits(det) and not vad.fits(dec)                      # the other architecture's state_dict
+    assert not decoder.fits(BidirectionalSpeechSynthesisModel(nb_layer=1, nb_hidden_units=100, nb_electrodes=64))
+    assert not decoder.fits(BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=129, nb_electrodes=64))
+    assert not decoder.fits(BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=257))
+    assert decoder.fits(BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=128, nb_electrodes=256))
+    assert not decoder.fits(object())
+    assert len(decoder._KEYS) == 18 and decoder._KEYS[0] == "lstm.weight_ih_l0" and decoder._KEYS[4] == "lstm.weight_ih_l0_reverse"
+    assert list(dec.state_dict().keys()) == list(decoder._KEYS)             # the C ABI takes the arrays in state_dict order
