@@ -58,7 +58,7 @@ dense_rows_kernel(const float *__restrict__ x, long x_utt_stride, int x_row_stri
     // the RT rows of the block, staged input-major ([input][row]): the products of one weight with two rows' inputs
     // are then one packed multiply (v_pk_mul_f32, the weight broadcast to both halves); the sums stay one per product
     extern __shared__ __attribute__((aligned(16))) float xs[];     // [M][RT]
-    static_assert(RT == 8, "staging and the packed products below are written for 8 rows per block");
+    static_assert(RT == 8 || RT == 4, "the packed products below take the rows in pairs");
     const int tid = threadIdx.x;
     const int i = blockIdx.y * 128 + tid;
     const int r0 = blockIdx.x * RT;
@@ -75,25 +75,38 @@ dense_rows_kernel(const float *__restrict__ x, long x_utt_stride, int x_row_stri
     __syncthreads();
     if (i >= N) return;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x2 acc[RT / 2];
     const float bi = bias[i];
 #pragma unroll
     for (int p = 0; p < RT / 2; ++p) acc[p] = (f32x2){bi, bi};
-    for (int j = 0; j < M; j += 2) {
+    // One input of all RT rows: the products first (a packed result needs a wait state before it can be read), then the sums:
+    // per row still "acc += w[j]*x[j]" in ascending j, each product and each sum rounded on its own (xiph sgemv_accum)
+#define DSS_DENSE_STEP2(J, W0, W1)                                                               \
+    {                                                                                            \
+        f32x2 pp[RT / 2], qq[RT / 2];                                                            \
+        _Pragma("unroll") for (int p = 0; p < RT / 2; ++p) {                                     \
+            pp[p] = (f32x2){W0, W0} * *reinterpret_cast<const f32x2 *>(&xs[(J) * RT + 2 * p]);   \
+            qq[p] = (f32x2){W1, W1} * *reinterpret_cast<const f32x2 *>(&xs[((J) + 1) * RT + 2 * p]); \
+        }                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < RT / 2; ++p) { acc[p].x += pp[p].x; acc[p].y += pp[p].y; } \
+        _Pragma("unroll") for (int p = 0; p < RT / 2; ++p) { acc[p].x += qq[p].x; acc[p].y += qq[p].y; } \
+    }
+    // eight weights per trip, all loads issued before the first product: two at a time, every pair of inputs waited for L2
+    // (18-26 us per launch for the 512 rows of a streaming tick)
+    int j = 0;
+    for (; j + 8 <= M; j += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = W[(size_t)(j + u) * N + i];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) DSS_DENSE_STEP2(j + u, wv[u], wv[u + 1])
+    }
+    for (; j < M; j += 2) {
         const float w0 = W[(size_t)(j + 0) * N + i];
         const float w1 = W[(size_t)(j + 1) * N + i];
-        const f32x4 xa = *reinterpret_cast<const f32x4 *>(&xs[(j + 0) * RT]), xb = *reinterpret_cast<const f32x4 *>(&xs[(j + 0) * RT + 4]);
-        const f32x4 xc = *reinterpret_cast<const f32x4 *>(&xs[(j + 1) * RT]), xd = *reinterpret_cast<const f32x4 *>(&xs[(j + 1) * RT + 4]);
-        // products first (a packed result needs a wait state before it can be read), then the sums: per row still
-        // "acc += w[j]*x[j]" in ascending j, each product and each sum rounded on its own (xiph sgemv_accum)
-        const f32x2 p0 = (f32x2){w0, w0} * xa.lo, p1 = (f32x2){w0, w0} * xa.hi, p2 = (f32x2){w0, w0} * xb.lo, p3 = (f32x2){w0, w0} * xb.hi;
-        const f32x2 q0 = (f32x2){w1, w1} * xc.lo, q1 = (f32x2){w1, w1} * xc.hi, q2 = (f32x2){w1, w1} * xd.lo, q3 = (f32x2){w1, w1} * xd.hi;
-        acc[0].x += p0.x; acc[0].y += p0.y; acc[1].x += p1.x; acc[1].y += p1.y;
-        acc[2].x += p2.x; acc[2].y += p2.y; acc[3].x += p3.x; acc[3].y += p3.y;
-        acc[0].x += q0.x; acc[0].y += q0.y; acc[1].x += q1.x; acc[1].y += q1.y;
-        acc[2].x += q2.x; acc[2].y += q2.y; acc[3].x += q3.x; acc[3].y += q3.y;
+        DSS_DENSE_STEP2(j, w0, w1)
     }
+#undef DSS_DENSE_STEP2
 #pragma unroll
     for (int rr = 0; rr < RT; ++rr) {
         const int r = r0 + rr;
@@ -120,12 +133,15 @@ frame_lpc_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, i
                  double idct_scale)
 {
     __shared__ float Xr[161][64];
+    __shared__ __attribute__((aligned(16))) float ck_lds[160][20];          // m.cos_kl ([bin][17 lags]) staged once per block: as scalar
+                                                                            //   loads inside the bin loop every bin waited for L2
     constexpr int eband5ms[DSS_NB_BANDS] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40};
     const int lane = threadIdx.x;
     int gid = blockIdx.x * 64 + lane;
     const bool valid = gid < total;
     if (!valid) gid = total - 1;
     const int utt = gid / n_frames, t = gid - utt * n_frames;
+    for (int k = lane; k < 160 * (DSS_LPC_ORDER + 1); k += 64) ck_lds[k / (DSS_LPC_ORDER + 1)][k % (DSS_LPC_ORDER + 1)] = m.cos_kl[k];
     const float *cep = feat + (size_t)gid * feat_stride;
     float c[DSS_NB_BANDS];
 #pragma unroll
@@ -149,6 +165,7 @@ frame_lpc_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, i
         }
     }
     Xr[160][lane] = 0.f;
+    __syncthreads();                                                        // ck_lds (one wave per block: LDS operations are in order anyway)
     float ac[DSS_LPC_ORDER + 1];
     {
         const float x0 = Xr[0][lane];
@@ -157,7 +174,7 @@ frame_lpc_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, i
     }
     for (int k = 1; k < 160; ++k) {                                         // direct inverse DFT, 17 lags, bins ascending
         const float x2 = 2.f * Xr[k][lane];
-        const float *ck = m.cos_kl + k * (DSS_LPC_ORDER + 1);
+        const float *ck = ck_lds[k];
 #pragma unroll
         for (int lag = 0; lag <= DSS_LPC_ORDER; ++lag) ac[lag] += x2 * ck[lag];
     }
@@ -262,11 +279,19 @@ static int launch_dense(const float *x, long xus, int xrs, const float *W, const
                         long ous, int ors, int ooff, int rows_per_utt, int total_rows, int zero_below, const int *fc0,
                         const float *tansig, hipStream_t s)
 {
-    constexpr int RT = 8;
-    dim3 grid((total_rows + RT - 1) / RT, (N + 127) / 128);
-    const size_t lds = (size_t)RT * M * sizeof(float);
-    hipLaunchKernelGGL((dense_rows_kernel<ACT, RT>), grid, dim3(128), lds, s, x, xus, xrs, W, bias, M, N, out, ous, ors, ooff,
-                       rows_per_utt, total_rows, zero_below, fc0, tansig);
+    // Rows per block: a thread's chain is RT sums per input, a block re-reads the layer's weights from L2.  Small calls (the
+    // 512 rows of a streaming tick: 64 blocks of 8 rows leave most CUs idle behind long chains) take 4 rows per block.
+    if (total_rows <= 2048) {
+        constexpr int RT = 4;
+        dim3 grid((total_rows + RT - 1) / RT, (N + 127) / 128);
+        hipLaunchKernelGGL((dense_rows_kernel<ACT, RT>), grid, dim3(128), (size_t)RT * M * sizeof(float), s, x, xus, xrs, W, bias, M, N, out,
+                           ous, ors, ooff, rows_per_utt, total_rows, zero_below, fc0, tansig);
+    } else {
+        constexpr int RT = 8;
+        dim3 grid((total_rows + RT - 1) / RT, (N + 127) / 128);
+        hipLaunchKernelGGL((dense_rows_kernel<ACT, RT>), grid, dim3(128), (size_t)RT * M * sizeof(float), s, x, xus, xrs, W, bias, M, N, out,
+                           ous, ors, ooff, rows_per_utt, total_rows, zero_below, fc0, tansig);
+    }
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }
