@@ -58,7 +58,7 @@ dense_rows_kernel(const float *__restrict__ x, long x_utt_stride, int x_row_stri
     // the RT rows of the block, staged input-major ([input][row]): the products of one weight with two rows' inputs
     // are then one packed multiply (v_pk_mul_f32, the weight broadcast to both halves); the sums stay one per product
     extern __shared__ __attribute__((aligned(16))) float xs[];     // [M][RT]
-    static_assert(RT == 8 || RT == 4, "the packed products below take the rows in pairs");
+    static_assert(RT == 8 || RT == 4 || RT == 2, "the packed products below take the rows in pairs");
     const int tid = threadIdx.x;
     const int i = blockIdx.y * 128 + tid;
     const int r0 = blockIdx.x * RT;
@@ -281,7 +281,12 @@ static int launch_dense(const float *x, long xus, int xrs, const float *W, const
 {
     // Rows per block: a thread's chain is RT sums per input, a block re-reads the layer's weights from L2.  Small calls (the
     // 512 rows of a streaming tick: 64 blocks of 8 rows leave most CUs idle behind long chains) take 4 rows per block.
-    if (total_rows <= 2048) {
+    if (total_rows <= 1024) {
+        constexpr int RT = 2;
+        dim3 grid((total_rows + RT - 1) / RT, (N + 127) / 128);
+        hipLaunchKernelGGL((dense_rows_kernel<ACT, RT>), grid, dim3(128), (size_t)RT * M * sizeof(float), s, x, xus, xrs, W, bias, M, N, out,
+                           ous, ors, ooff, rows_per_utt, total_rows, zero_below, fc0, tansig);
+    } else if (total_rows <= 2048) {
         constexpr int RT = 4;
         dim3 grid((total_rows + RT - 1) / RT, (N + 127) / 128);
         hipLaunchKernelGGL((dense_rows_kernel<ACT, RT>), grid, dim3(128), (size_t)RT * M * sizeof(float), s, x, xus, xrs, W, bias, M, N, out,
