@@ -120,102 +120,95 @@ dense_rows_kernel(const float *__restrict__ x, long x_utt_stride, int x_row_stri
     }
 }
 
-// ---- lpc_from_cepstrum (freq.c) for every (utterance, frame): one lane per frame ------------------------------
-// Each lane runs the whole chain of its frame -- inverse DCT of the cepstrum, band interpolation, the 17 autocorrelation
-// lags as a direct inverse DFT (160 terms each, in ascending bin order), lag window, Levinson-Durbin -- with the
-// reference's operation order; the per-bin and per-(bin, lag) constants are wave-uniform (scalar loads), the
-// interpolated spectrum of a lane lives in LDS ([bin][lane], conflict-free).
+// ---- lpc_from_cepstrum (freq.c) for every (utterance, frame): 32 lanes per frame -----------------------------
+// The chain of a frame -- inverse DCT of the cepstrum, band energies, band interpolation, the 17 autocorrelation lags as a
+// direct inverse DFT (160 terms each, in ascending bin order), lag window, Levinson-Durbin -- with the reference's operation
+// order inside every element; what is independent runs on different lanes: one band per lane, one bin per lane, one LAG per
+// lane (its 160-term sum stays one sequential chain), and the recursion on one lane.  One lane per frame (rounds 1-3) took
+// 60 us whatever the batch: 160 x 17 dependent pairs of instructions per lane behind scalar loads of the cosine table.
 __constant__ float c_compensation[DSS_NB_BANDS] = {0.8f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.666667f, 0.5f, 0.5f, 0.5f,
                                                    0.333333f, 0.25f, 0.25f, 0.2f, 0.166667f, 0.173913f};
+#define LPC_FPB 2                 // frames per 64-thread block
 
 __global__ void __launch_bounds__(64)
 frame_lpc_kernel(DssModelDev m, DssBatchDev b, const float *__restrict__ feat, int total, int n_frames, int feat_stride,
                  double idct_scale)
 {
-    __shared__ float Xr[161][64];
-    __shared__ __attribute__((aligned(16))) float ck_lds[160][20];          // m.cos_kl ([bin][17 lags]) staged once per block: as scalar
-                                                                            //   loads inside the bin loop every bin waited for L2
+    __shared__ __attribute__((aligned(16))) float ck_lds[160][20];          // m.cos_kl ([bin][17 lags])
+    __shared__ float cs[LPC_FPB][DSS_NB_BANDS + 2], exs[LPC_FPB][DSS_NB_BANDS + 2], xr[LPC_FPB][160], as[LPC_FPB][DSS_LPC_ORDER + 4];
     constexpr int eband5ms[DSS_NB_BANDS] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40};
-    const int lane = threadIdx.x;
-    int gid = blockIdx.x * 64 + lane;
+    const int tid = threadIdx.x, sub = tid >> 5, l = tid & 31;
+    int gid = blockIdx.x * LPC_FPB + sub;
     const bool valid = gid < total;
     if (!valid) gid = total - 1;
     const int utt = gid / n_frames, t = gid - utt * n_frames;
-    for (int k = lane; k < 160 * (DSS_LPC_ORDER + 1); k += 64) ck_lds[k / (DSS_LPC_ORDER + 1)][k % (DSS_LPC_ORDER + 1)] = m.cos_kl[k];
+    for (int k = tid; k < 160 * (DSS_LPC_ORDER + 1); k += 64) ck_lds[k / (DSS_LPC_ORDER + 1)][k % (DSS_LPC_ORDER + 1)] = m.cos_kl[k];
     const float *cep = feat + (size_t)gid * feat_stride;
-    float c[DSS_NB_BANDS];
-#pragma unroll
-    for (int j = 0; j < DSS_NB_BANDS; ++j) c[j] = cep[j];
-    c[0] += 4;
-    float Ex[DSS_NB_BANDS];
-#pragma unroll
-    for (int i = 0; i < DSS_NB_BANDS; ++i) {
+    if (l < DSS_NB_BANDS) cs[sub][l] = l == 0 ? cep[0] + 4 : cep[l];
+    __syncthreads();
+    if (l < DSS_NB_BANDS) {                                                 // band l: inverse DCT term by term, then the energy
         float sum = 0;
 #pragma unroll
-        for (int j = 0; j < DSS_NB_BANDS; ++j) sum += c[j] * m.dct_table[i * DSS_NB_BANDS + j];
+        for (int j = 0; j < DSS_NB_BANDS; ++j) sum += cs[sub][j] * m.dct_table[l * DSS_NB_BANDS + j];
         const float e = (float)((double)sum * idct_scale);                 // sum*sqrt(2./NB_BANDS)
-        Ex[i] = (float)(pow(10.0, (double)e) * (double)c_compensation[i]);
+        exs[sub][l] = (float)(pow(10.0, (double)e) * (double)c_compensation[l]);
     }
+    __syncthreads();
+    for (int k = l; k < 160; k += 32) {                                     // interp_band_gain: bin k lies in band i
+        int i = 0;
 #pragma unroll
-    for (int i = 0; i < DSS_NB_BANDS - 1; ++i) {                            // interp_band_gain
-#pragma unroll
-        for (int j = 0; j < (eband5ms[i + 1] - eband5ms[i]) * 4; ++j) {
-            const int k = eband5ms[i] * 4 + j;
-            Xr[k][lane] = m.interp_a[k] * Ex[i] + m.interp_b[k] * Ex[i + 1];
+        for (int q = 1; q < DSS_NB_BANDS - 1; ++q) i += (k >= eband5ms[q] * 4);
+        xr[sub][k] = m.interp_a[k] * exs[sub][i] + m.interp_b[k] * exs[sub][i + 1];
+    }
+    __syncthreads();
+    if (l <= DSS_LPC_ORDER) {                                               // lag l: direct inverse DFT, bins ascending
+        float ac = xr[sub][0];
+        for (int k = 1; k < 160; ++k) {
+            const float x2 = 2.f * xr[sub][k];
+            ac += x2 * ck_lds[k][l];
         }
+        float a;
+        if (l == 0) a = (float)((double)ac + ((double)ac * 1e-4 + 320 / 12 / 38.));
+        else a = (float)((double)ac * m.lag_window[l]);
+        as[sub][l] = a;
     }
-    Xr[160][lane] = 0.f;
-    __syncthreads();                                                        // ck_lds (one wave per block: LDS operations are in order anyway)
-    float ac[DSS_LPC_ORDER + 1];
-    {
-        const float x0 = Xr[0][lane];
+    __syncthreads();
+    if (l == 0) {                                                           // Levinson-Durbin (the recursion is serial)
+        float a[DSS_LPC_ORDER + 1];
 #pragma unroll
-        for (int lag = 0; lag <= DSS_LPC_ORDER; ++lag) ac[lag] = x0;
-    }
-    for (int k = 1; k < 160; ++k) {                                         // direct inverse DFT, 17 lags, bins ascending
-        const float x2 = 2.f * Xr[k][lane];
-        const float *ck = ck_lds[k];
+        for (int i = 0; i <= DSS_LPC_ORDER; ++i) a[i] = as[sub][i];
+        float lpc[DSS_LPC_ORDER];
 #pragma unroll
-        for (int lag = 0; lag <= DSS_LPC_ORDER; ++lag) ac[lag] += x2 * ck[lag];
-    }
-    float a[DSS_LPC_ORDER + 1];
+        for (int i = 0; i < DSS_LPC_ORDER; ++i) lpc[i] = 0.f;
+        float error = a[0];
+        bool live = a[0] != 0;
 #pragma unroll
-    for (int i = 0; i <= DSS_LPC_ORDER; ++i) a[i] = ac[i];
-    a[0] = (float)((double)a[0] + ((double)a[0] * 1e-4 + 320 / 12 / 38.));
+        for (int i = 0; i < DSS_LPC_ORDER; i++) {
+            if (live) {
+                float rr = 0;
 #pragma unroll
-    for (int i = 1; i <= DSS_LPC_ORDER; ++i) a[i] = (float)((double)a[i] * m.lag_window[i]);
-    float lpc[DSS_LPC_ORDER];
+                for (int j = 0; j < i; j++) rr += lpc[j] * a[i - j];
+                rr += a[i + 1];
+                const float r = -rr / error;
+                lpc[i] = r;
 #pragma unroll
-    for (int i = 0; i < DSS_LPC_ORDER; ++i) lpc[i] = 0.f;
-    float error = a[0];
-    bool live = a[0] != 0;
-#pragma unroll
-    for (int i = 0; i < DSS_LPC_ORDER; i++) {
-        if (live) {
-            float rr = 0;
-#pragma unroll
-            for (int j = 0; j < i; j++) rr += lpc[j] * a[i - j];
-            rr += a[i + 1];
-            const float r = -rr / error;
-            lpc[i] = r;
-#pragma unroll
-            for (int j = 0; j < (i + 1) >> 1; j++) {
-                const float tmp1 = lpc[j], tmp2 = lpc[i - 1 - j];
-                lpc[j] = tmp1 + r * tmp2;
-                lpc[i - 1 - j] = tmp2 + r * tmp1;
+                for (int j = 0; j < (i + 1) >> 1; j++) {
+                    const float tmp1 = lpc[j], tmp2 = lpc[i - 1 - j];
+                    lpc[j] = tmp1 + r * tmp2;
+                    lpc[i - 1 - j] = tmp2 + r * tmp1;
+                }
+                error = error - (r * r) * error;
+                if (error < .001f * a[0]) live = false;                      // the C loop's break
             }
-            error = error - (r * r) * error;
-            if (error < .001f * a[0]) live = false;                          // the C loop's break
         }
-    }
-    if (valid) {
-        float *dst = b.lpc_buf + ((size_t)utt * (n_frames + 2) + t + 2) * 16;
+        if (valid) {
+            float *dst = b.lpc_buf + ((size_t)utt * (n_frames + 2) + t + 2) * 16;
 #pragma unroll
-        for (int i = 0; i < DSS_LPC_ORDER; ++i) dst[i] = lpc[i];
+            for (int i = 0; i < DSS_LPC_ORDER; ++i) dst[i] = lpc[i];
+        }
     }
 }
 
-// ---- self-test of the one transcendental this path evaluates on the device ------------------------------------------
 // lpc_from_cepstrum's `pow(10.f, Ex[i]) * compensation[i]` (freq.c) is a double pow rounded to float after the
 // multiplication; the LPC taps are bit-exact only if the device's pow and the host libm's agree after that rounding.
 // tests/test_gpu_lpcnet.py sweeps the reachable exponent range through this kernel (same expression as line 141).
@@ -328,7 +321,7 @@ int dss_launch_frame_network(const DssModelDev &m, DssBatchDev &b, const float *
                                   b.frame_out, (long)F * DSS_COND_STRIDE, DSS_COND_STRIDE, 3 * DSS_GRU_A, F, rows, 0, b.fc0,
                                   m.tansig, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(frame_lpc_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, m, b, d_features, rows, F, feat_stride,
+    hipLaunchKernelGGL(frame_lpc_kernel, dim3((rows + LPC_FPB - 1) / LPC_FPB), dim3(64), 0, s, m, b, d_features, rows, F, feat_stride,
                        sqrt(2. / DSS_NB_BANDS));
     DSS_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(frame_finish_kernel, dim3(F + 1, B), dim3(128), 0, s, b, F);
