@@ -19,13 +19,16 @@ def model(oracle):
     return oracle.lpcnet_model(blob)
 
 
-def test_frame_network_taps_bit_exact(oracle, model):
+@pytest.mark.parametrize("B,F", [(3, 12), (1, 1), (13, 100), (25, 101)])
+def test_frame_network_taps_bit_exact(oracle, model, B, F):
+    """The frame-rate network's three outputs per frame against the oracle, at row counts that take each of the dense layers'
+    block shapes (2 rows per block up to 1024 rows, 4 up to 2048, 8 beyond) and an odd number of frames (frame_lpc_kernel
+    takes two per block)."""
     from dss_amd.lpcnet import LPCNetBatch
-    B, F = 3, 12
     feats = np.stack([synthetic_features(40 + b, F) for b in range(B)])
     gpu = LPCNetBatch(B, F)
     gpu.synthesize(feats)
-    for b in range(B):
+    for b in sorted({0, B // 2, B - 1}):
         dec = oracle.decoder(model)
         for t in range(F):
             dec.frame_network(feats[b, t])
