@@ -260,7 +260,7 @@ struct SampleLds {
     }
 
 // =====================================================================================================
-// role A: GRU A (+ dual-FC on waves 0..3, + the speculation on waves 4..5).  Two instantiations share this text:
+// role A: GRU A (+ dual-FC on waves 0..3, + the speculation on waves 0, 1 and DSS_SPEC_WAVE).  Two instantiations share this text:
 //   waves 0..3  HAS_FC, at most 8 z/r register slots per gate (the dual-FC weights take 32 registers);
 //   waves 4..5  no dual-FC, all Z slots -- the host gives them the row groups with the most z/r blocks.
 // Keeping the two apart is what keeps either under the 256-VGPR budget without spill reloads in the sample loop.
@@ -420,7 +420,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
             DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
             if (wave == DSS_SPEC_WAVE || wave < 2) {
-                // Speculation over all 256 possible excitation values of THIS sample, one candidate per lane of wave 5
+                // Speculation over all 256 possible excitation values of THIS sample, one candidate per lane of wave DSS_SPEC_WAVE
                 // (candidates 64..127), of waves 0, 1, which have the lightest B..C load of the dual-FC waves (128..255),
                 // and of wave 6 once it has handed its half of the GRU B chain over (0..63): the next sample's LPC prediction and mu-law indices, so that once the tree walk has
                 // picked the value nobody has to run the two ~40-step dependent chains.  Same expressions, same order
