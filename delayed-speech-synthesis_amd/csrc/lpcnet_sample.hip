@@ -108,8 +108,8 @@ struct SampleLds {
     float ulaw2lin[256];
     float spec_tab_pred[256];             // speculation over all 256 excitation values (see role A, B..C):
     unsigned short spec_tab_idx[256];     //   next sample's prediction and its two mu-law indices (su | pu << 8)
-    float spec_ls[DSS_LPC_ORDER];         // inputs of the speculation, published by wave 7: signal history,
-    float spec_lpc[DSS_LPC_ORDER];        //   the LPC of the next sample's frame,
+    float spec_prod[DSS_LPC_ORDER];       // inputs of the speculation, published by wave 7: [0] = lpc[0] of the next sample's frame,
+                                          //   [j] = history[j-1] * lpc[j] (these products are the same for every candidate),
     float spec_pred;                      //   and this sample's prediction
     float pad1[3];
     float gb_acc[64][2];                  // GRU B running sums handed between the relay waves: (sum, 4 * sample number + segments done)
@@ -231,8 +231,8 @@ struct SampleLds {
         const int cand_ = (CAND);                                                                \
         const float pcm_c = L.spec_pred + L.ulaw2lin[cand_];                                     \
         float pc = 0;                                                                            \
-        pc -= pcm_c * L.spec_lpc[0];                                                             \
-        _Pragma("unroll") for (int j = 1; j < DSS_LPC_ORDER; ++j) pc -= L.spec_ls[j - 1] * L.spec_lpc[j]; \
+        pc -= pcm_c * L.spec_prod[0];                                                            \
+        _Pragma("unroll") for (int j = 1; j < DSS_LPC_ORDER; ++j) pc -= L.spec_prod[j];          \
         const int su_c = dss_lin2ulaw(pcm_c), pu_c = dss_lin2ulaw(pc);                           \
         L.spec_tab_pred[cand_] = pc;                                                             \
         L.spec_tab_idx[cand_] = (unsigned short)(su_c | (pu_c << 8));                            \
@@ -428,9 +428,9 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 const int cand = HAS_FC ? 128 + tid : tid - 64 * DSS_SPEC_WAVE + 64;
                 const float pcm_c = L.spec_pred + u2l_c;
                 float pc = 0;
-                pc -= pcm_c * L.spec_lpc[0];
+                pc -= pcm_c * L.spec_prod[0];
 #pragma unroll
-                for (int j = 1; j < DSS_LPC_ORDER; ++j) pc -= L.spec_ls[j - 1] * L.spec_lpc[j];
+                for (int j = 1; j < DSS_LPC_ORDER; ++j) pc -= L.spec_prod[j];       // (history[j-1] * lpc[j], formed once by wave 7)
                 const int su_c = dss_lin2ulaw(pcm_c), pu_c = dss_lin2ulaw(pc);
                 L.spec_tab_pred[cand] = pc;
                 L.spec_tab_idx[cand] = (unsigned short)(su_c | (pu_c << 8));
@@ -673,10 +673,13 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     const bool last_of_frame = (i == DSS_FRAME_SIZE - 1);
                     next_exists = !(last_of_frame && f == nf - 1);
                     float lp = lpc_lane;                     // lane j < 16 publishes element j
-                    const float ls = ls_lane;
                     if (last_of_frame && next_exists && lane < DSS_LPC_ORDER)
                         lp = b.frame_out[((size_t)utt * n_frames + f + 1) * DSS_COND_STRIDE + 3 * NA + NB3 + lane];
-                    if (lane < DSS_LPC_ORDER) { L.spec_lpc[lane] = lp; L.spec_ls[lane] = ls; }
+                    // history[j-1] arrives in lane j (row_shr:1): the 15 products history[j-1] * lpc[j] of the next prediction
+                    // do not depend on the candidate, so they are formed here once instead of by every speculating lane
+                    const float ls_up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ls_lane), 0x111, 0xf, 0xf, false));
+                    const float prod = ls_up * lp;
+                    if (lane < DSS_LPC_ORDER) L.spec_prod[lane] = lane ? prod : lp;
                     if (lane == 0) L.spec_pred = pred;
                 }
                 float rec = gbb1;
