@@ -300,15 +300,17 @@ __device__ __forceinline__ void dss_pair_job_init(PairLds &L, const DssBatchDev 
 // weights of block g sit in RW[g] (four inputs of this lane's row, loaded from m.gb_w_quad); once a block is multiplied
 // its weight registers are reloaded with block g of the wave's NEXT stage (first block GN), which is multiplied a sum
 // stage and a hand-over later: the L2 latency never shows.
+#ifndef DSS_PRD
+#define DSS_PRD 2                 // blocks of state pairs read ahead of the products
+#endif
 #define DSS_PR_MUL(NBK, G0, GN)                                                                  \
     {                                                                                            \
-        PairX RX[3];                                                                             \
-        dss_pair_loadx(RX[0], an + 32 * (G0));                                                   \
-        dss_pair_loadx(RX[1], an + 32 * ((G0) + 1));                                             \
+        PairX RX[DSS_PRD + 1];                                                                   \
+        _Pragma("unroll") for (int u = 0; u < DSS_PRD; ++u) dss_pair_loadx(RX[u], an + 32 * ((G0) + u)); \
         _Pragma("unroll") for (int g = 0; g < (NBK); ++g) {                                      \
-            if (g + 2 < (NBK)) dss_pair_loadx(RX[(g + 2) % 3], an + 32 * ((G0) + g + 2));        \
+            if (g + DSS_PRD < (NBK)) dss_pair_loadx(RX[(g + DSS_PRD) % (DSS_PRD + 1)], an + 32 * ((G0) + g + DSS_PRD)); \
             __builtin_amdgcn_sched_barrier(0);                                                   \
-            DSS_PK_MUL4(PS[g], RX[g % 3], RW[g].lo, RW[g].hi);                                   \
+            DSS_PK_MUL4(PS[g], RX[g % (DSS_PRD + 1)], RW[g].lo, RW[g].hi);                       \
             __builtin_amdgcn_sched_barrier(0);                                                   \
             RW[g] = *reinterpret_cast<const f32x4 *>(wq + (wo + (unsigned)((GN) + g) * 1024u));  \
         }                                                                                        \
