@@ -10,6 +10,8 @@ What it does before handing control to the script (runpy, ``__main__``):
      run directly) and replaces in them exactly the classes whose work moves to the GPU:
         local.units.HighGammaExtractor      -> dss_amd.units.HighGammaExtractor      (fused IIR + framing + log power)
         local.units.DelayedLPCNetVocoder    -> dss_amd.units.DelayedLPCNetVocoder    (whole segment per launch)
+        local.units.RecurrentNeuralDecodingModel -> dss_amd.units.RecurrentNeuralDecodingModel (the reference's decoder
+                                               architecture on the library's kernels; other modules as they are)
         local.training.AsynchronousSynthesisQueue -> dss_amd.synthesis_queue.AsynchronousSynthesisQueue
      ``HighGammaActivity.initialize`` (units.py:199-201) looks HighGammaExtractor up in its module at run time, so the
      reference's own unit class picks the GPU extractor up; every other unit is the user's code, untouched.
@@ -33,6 +35,7 @@ def install(verbose: bool = True) -> dict:
     report = {}
     swaps = (("local.units", "HighGammaExtractor", "dss_amd.units"),
              ("local.units", "DelayedLPCNetVocoder", "dss_amd.units"),
+             ("local.units", "RecurrentNeuralDecodingModel", "dss_amd.units"),
              ("local.training", "AsynchronousSynthesisQueue", "dss_amd.synthesis_queue"))
     for mod_name, attr, ours in swaps:
         key = f"{mod_name}.{attr}"

@@ -142,6 +142,7 @@ def test_runner_swaps_the_gpu_units_into_an_unchanged_user_script(tmp_path):
         from hga_optimized import WarmStartFrameBuffer
         class HighGammaExtractor: origin = 'user'
         class DelayedLPCNetVocoder: origin = 'user'
+        class RecurrentNeuralDecodingModel: origin = 'user'
         class BinaryLogger: origin = 'user'
         class HighGammaActivity:
             def make(self):
@@ -149,11 +150,12 @@ def test_runner_swaps_the_gpu_units_into_an_unchanged_user_script(tmp_path):
     """))
     (tmp_path / "script.py").write_text(textwrap.dedent("""
         import sys
-        from local.units import HighGammaActivity, DelayedLPCNetVocoder, BinaryLogger
+        from local.units import HighGammaActivity, DelayedLPCNetVocoder, RecurrentNeuralDecodingModel, BinaryLogger
         import LPCNet
         print('ARGS', sys.argv[1:])
         print('EXT', HighGammaActivity().make().__module__)
         print('VOC', DelayedLPCNetVocoder.__module__)
+        print('DEC', RecurrentNeuralDecodingModel.__module__)
         print('LOG', BinaryLogger.origin)
         print('LPCNET', LPCNet.__file__)
     """))
@@ -163,6 +165,7 @@ def test_runner_swaps_the_gpu_units_into_an_unchanged_user_script(tmp_path):
     assert out.returncode == 0, out.stderr
     assert "ARGS ['cfg.ini', '--run']" in out.stdout
     assert "EXT dss_amd.units" in out.stdout and "VOC dss_amd.units" in out.stdout and "LOG user" in out.stdout
+    assert "DEC dss_amd.units" in out.stdout and "local.units.RecurrentNeuralDecodingModel: replaced" in out.stderr
     assert os.path.join("delayed-speech-synthesis_amd", "LPCNet.py") in out.stdout
     assert "local.units.HighGammaExtractor: replaced" in out.stderr
     assert "local.training.AsynchronousSynthesisQueue: left alone" in out.stderr      # this user tree has no training.py
@@ -184,3 +187,31 @@ def test_kernel_fit_checks_of_the_recurrent_models():
     assert not decoder.fits(object())
     assert len(decoder._KEYS) == 18 and decoder._KEYS[0] == "lstm.weight_ih_l0" and decoder._KEYS[4] == "lstm.weight_ih_l0_reverse"
     assert list(dec.state_dict().keys()) == list(decoder._KEYS)             # the C ABI takes the arrays in state_dict order
+
+
+def test_decoder_unit_on_the_host_path(golden, tmp_path):
+    """RecurrentNeuralDecodingModel without a GPU: built from settings and a state_dict file like the reference's unit
+    (units.py:481-497), one segment in, (L, 20) features at 100 Hz out, equal to the reference-built golden vector."""
+    import asyncio
+    import dss_amd.units as U
+    from dss_amd.models import BidirectionalSpeechSynthesisModel
+    g = golden("models.npz")
+    torch.manual_seed(0)
+    ref = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64)
+    path = tmp_path / "decoder.pth"
+    torch.save(ref.state_dict(), path)
+    unit = U.RecurrentNeuralDecodingModel(U.RecurrentNeuralDecodingModelSettings(
+        path_to_model_weights=str(path), model=BidirectionalSpeechSynthesisModel,
+        params=dict(nb_layer=2, nb_hidden_units=100, nb_electrodes=64)))
+    unit.initialize()
+
+    async def drive(gen):
+        return [item async for item in gen]
+    seg = g["bilstm_in"][0].astype(np.float64)             # the unit casts to float32 itself (units.py:503)
+    for _ in range(2):                                     # a fresh state per segment: the same answer twice
+        (stream, msg), = asyncio.run(drive(unit.decode(U.ClosedLoopMessage(data=seg, fs=100, previous_frames=7))))
+        assert stream is unit.OUTPUT and msg.fs == 100 and msg.previous_frames == 7
+        assert msg.data.shape == (100, 20) and msg.data.dtype == np.float32
+        np.testing.assert_allclose(msg.data, g["bilstm_out"][0], rtol=0, atol=2e-5)
+    if not torch.cuda.is_available():
+        assert unit.STATE.kernel is None and unit.STATE.device == "cpu"

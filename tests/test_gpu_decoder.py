@@ -101,3 +101,41 @@ def test_pipelines_with_the_decoder_kernel_agree_with_the_torch_decoder():
         assert ya.shape == yb.shape
         assert torch.equal(sk.last_hga, sm.last_hga)
         assert (sk.last_feats - sm.last_feats).abs().max().item() <= 2e-5
+
+
+def test_decoder_unit_runs_the_kernels_for_the_reference_architecture(golden, tmp_path):
+    """dss_amd.units.RecurrentNeuralDecodingModel (the surface of units.py:450-508) on the GPU box: the reference's
+    architecture takes the kernel path (golden features within 2e-5, the PyTorch-ROCm module within 2e-5, a fresh state per
+    segment, segments of different lengths), a model of another architecture stays on the module."""
+    import asyncio
+    import dss_amd.units as U
+    from dss_amd.models import BidirectionalSpeechSynthesisModel
+    g = golden("models.npz")
+    ref = _model()
+    path = tmp_path / "decoder.pth"
+    torch.save(ref.state_dict(), path)
+    unit = U.RecurrentNeuralDecodingModel(U.RecurrentNeuralDecodingModelSettings(
+        path_to_model_weights=str(path), model=BidirectionalSpeechSynthesisModel,
+        params=dict(nb_layer=2, nb_hidden_units=100, nb_electrodes=64)))
+    unit.initialize()
+    assert unit.STATE.kernel is not None and unit.STATE.device == "cuda"
+
+    async def drive(gen):
+        return [item async for item in gen]
+    x = g["bilstm_in"][0]
+    mg = ref.cuda()
+    for L in (100, 37, 1, 100):
+        (stream, msg), = asyncio.run(drive(unit.decode(U.ClosedLoopMessage(data=x[:L].astype(np.float64), fs=100))))
+        assert stream is unit.OUTPUT and msg.fs == 100 and msg.data.shape == (L, 20) and msg.data.dtype == np.float32
+        with torch.no_grad():
+            want, _ = mg(torch.from_numpy(x[:L])[None].cuda(), mg.create_new_initial_state(batch_size=1, device="cuda"))
+        assert np.abs(msg.data - want[0].cpu().numpy()).max() <= 2e-5
+        if L == 100:
+            assert np.abs(msg.data - g["bilstm_out"][0]).max() <= 2e-5
+    other = U.RecurrentNeuralDecodingModel(U.RecurrentNeuralDecodingModelSettings(
+        path_to_model_weights=None, model=BidirectionalSpeechSynthesisModel,
+        params=dict(nb_layer=3, nb_hidden_units=24, nb_electrodes=64)))
+    other.initialize()
+    assert other.STATE.kernel is None
+    (_, msg), = asyncio.run(drive(other.decode(U.ClosedLoopMessage(data=x[:9].astype(np.float64), fs=100))))
+    assert msg.data.shape == (9, 20)
