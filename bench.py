@@ -419,6 +419,35 @@ def main():
                   "x_realtime": 10.0 / float(np.percentile(l1, 50))}
         del net
 
+    # Row a11 on its own: the decoder kernels (csrc/bilstm_decoder.hip, three launches per call) next to the same weights as the
+    # PyTorch-ROCm module (MIOpen's launch chain), device time per call for the two shapes the lines above contain
+    decoder_ms = None
+    if extras:
+        from dss_amd.decoder import BiLstmDecoderGPU
+        from dss_amd.models import BidirectionalSpeechSynthesisModel
+        torch.manual_seed(0)
+        mod = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64).eval().cuda()
+
+        def _dev_ms(fn, n=30):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        decoder_ms = {"model": "BidirectionalSpeechSynthesisModel(2 layers x 100 hidden units, 64 inputs), seeded weights, zero state per call"}
+        for S_, T_, tag in ((128, 4, "128_streams_x_4_frames"), (64, 104, "64_segments_x_104_frames")):
+            kd = BiLstmDecoderGPU(S_, T_, mod)
+            zd = torch.randn((S_, T_, 64), dtype=torch.float64, device="cuda")
+            with torch.no_grad():
+                tm = _dev_ms(lambda: mod(zd.to(torch.float32), mod.create_new_initial_state(batch_size=S_, device="cuda")))
+            decoder_ms[tag] = {"kernels_ms": _dev_ms(lambda: kd(zd)), "pytorch_rocm_module_ms": tm}
+            del kd
+
     # HBM traffic and issue counters of the dominant kernel per launch: PMC counters cannot be read from inside this
     # process, so they come from the committed rocprofv3 --pmc passes of this same command (profiles/), and are quoted
     # only for the workload they were taken on
@@ -493,6 +522,7 @@ def main():
             "latency": latency,
             "latency_gated": latency_gated,
             "level1": level1,
+            "decoder": decoder_ms,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
