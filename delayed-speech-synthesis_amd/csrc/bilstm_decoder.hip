@@ -197,6 +197,7 @@ int dss_launch_decoder(const DssDecDev &d, const void *d_frames, int frames_f64,
         dss_set_error("decoder kernel: hidden size %d / %d inputs out of range (<= %d / <= %d)", d.H, d.C, DEC_MAXH, DEC_MAXC);
         return DSS_EINVAL;
     }
+    if (d.O < 1 || d.O > 32) { dss_set_error("decoder kernel: %d outputs out of range (<= 32)", d.O); return DSS_EINVAL; }
     if (S < 1 || S > d.S_max || T < 1 || T > d.T_max) {
         dss_set_error("decoder kernel: %d streams x %d frames exceed the handle's %d x %d", S, T, d.S_max, d.T_max);
         return DSS_EINVAL;

@@ -29,7 +29,7 @@ def fits(module) -> bool:
     h4, c = sd["lstm.weight_ih_l0"].shape
     h = h4 // 4
     o = sd["regressor.weight"].shape[0]
-    ok = h4 == 4 * h and 1 <= h <= 128 and 1 <= c <= 256 and 1 <= o <= 64
+    ok = h4 == 4 * h and 1 <= h <= 128 and 1 <= c <= 256 and 1 <= o <= 32
     for rev in ("", "_reverse"):
         ok = ok and tuple(sd[f"lstm.weight_ih_l0{rev}"].shape) == (h4, c) and tuple(sd[f"lstm.weight_hh_l0{rev}"].shape) == (h4, h)
         ok = ok and tuple(sd[f"lstm.weight_ih_l1{rev}"].shape) == (h4, 2 * h) and tuple(sd[f"lstm.weight_hh_l1{rev}"].shape) == (h4, h)

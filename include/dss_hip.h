@@ -301,7 +301,7 @@ int dss_vad_state(dss_vad *v, float *h, float *c, int set);
  * architecture stays a PyTorch-ROCm module (dss_amd/pipeline.py falls back to it).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct dss_dec dss_dec;
-dss_dec *dss_dec_create(int max_streams, int max_frames, int n_inputs /* <= 256 */, int hidden_units /* <= 128 */, int n_outputs);
+dss_dec *dss_dec_create(int max_streams, int max_frames, int n_inputs /* <= 256 */, int hidden_units /* <= 128 */, int n_outputs /* <= 32 */);
 void dss_dec_destroy(dss_dec *v);
 /* w: 18 host arrays in torch.nn.LSTM's own layout (state_dict of the reference class, gate order i, f, g, o):
  * for layer l in (0, 1), for (forward, reverse): lstm.weight_ih_l{l}[_reverse] [4H][Cin], lstm.weight_hh_l{l}[_reverse] [4H][H],

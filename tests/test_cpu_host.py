@@ -185,6 +185,9 @@ def test_kernel_fit_checks_of_the_recurrent_models():
     assert not decoder.fits(BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=257))
     assert decoder.fits(BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=128, nb_electrodes=256))
     assert not decoder.fits(object())
+    wide = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64)
+    wide.regressor = torch.nn.Linear(200, 40)                               # more outputs than the regressor kernel stages in LDS
+    assert not decoder.fits(wide)
     assert len(decoder._KEYS) == 18 and decoder._KEYS[0] == "lstm.weight_ih_l0" and decoder._KEYS[4] == "lstm.weight_ih_l0_reverse"
     assert list(dec.state_dict().keys()) == list(decoder._KEYS)             # the C ABI takes the arrays in state_dict order
 
