@@ -9,6 +9,6 @@ from dss_amd.lpcnet import load_model
 from dss_amd.lpcnet_weights import synthetic_blob
 from dss_amd.pipeline import StreamingPipeline
 load_model(synthetic_blob(0))
-p = StreamingPipeline(128, 64)
+p = StreamingPipeline(128, 64, use_graph=os.environ.get("USE_GRAPH", "1") == "1")
 lat = p.measure_latency(int(os.environ.get("TICKS", "200")))
 print("p50 %.3f ms  p99 %.3f ms" % (np.percentile(lat[20:], 50), np.percentile(lat[20:], 99)))
