@@ -18,13 +18,9 @@
 // (stream, unit).  Time steps are sequential; streams x gate rows x directions are the parallel axes.
 #include "dss_common.h"
 
-#define DEC_SPW_MAX 4             // streams per workgroup: 1, 2 or 4 (template parameter W), chosen per call so that the grid fills the chip
 #define DEC_THREADS 512           // >= 4 * H and >= W * H
 #define DEC_MAXH 128              // (a multiple of 4)
 #define DEC_MAXC 256              // inputs of a layer: n_inputs for layer 0, 2H above it
-#ifndef DEC_INFLIGHT
-#define DEC_INFLIGHT 8
-#endif
 #define DEC_TP 4                  // steps whose input halves (W_ih x) are formed in one pass over W_ih
 
 typedef float df4 __attribute__((ext_vector_type(4)));
