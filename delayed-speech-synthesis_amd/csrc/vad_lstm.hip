@@ -8,29 +8,33 @@
 // (the test states it: |logit - torch| <= 2e-5 on the reference-generated golden vector, equal labels on random frames) and
 // fused multiply-adds are allowed -- unlike everywhere else in this library.  Gate order i, f, g, o (torch.nn.LSTM).
 //
-// One launch per tick instead of MIOpen's chain of small launches per layer and frame: a 640-thread workgroup owns VAD_SPW
+// One launch per tick instead of MIOpen's chain of small launches per layer and frame: a 640-thread workgroup owns SW (1 or 2)
 // streams for the whole call; thread t owns gate row t (4H = 600 rows) of the layer being stepped and runs the row's
-// dot product for all VAD_SPW streams at once: the weights (copies with four consecutive inputs of a row side by side: one
-// 16-byte load per lane, 1 KB of consecutive bytes per wave) come from L2 once per workgroup, the inputs of the VAD_SPW
+// dot product for all SW streams at once: the weights (copies with four consecutive inputs of a row side by side: one
+// 16-byte load per lane, 1 KB of consecutive bytes per wave) come from L2 once per workgroup, the inputs of the SW
 // streams from LDS as broadcast reads.  h lives in LDS, c
 // in the registers of the thread that owns (stream, unit).  The time steps and the two layers are sequential; streams x
 // gate rows are the parallel axes.  Weights 1.24 MB fp32 for H = 150: L2-resident after the first workgroup has read them.
 #include "dss_common.h"
 
-#define VAD_SPW 2                 // streams per workgroup
 #define VAD_THREADS 640           // >= 4 * H
 #define VAD_MAXH 160              // (a multiple of 4)
 #define VAD_MAXC 128
+#define VAD_TP 4                  // frames whose input halves (W_ih x) are formed in one pass over W_ih
 
-typedef float vf2 __attribute__((ext_vector_type(2)));
 typedef float vf4 __attribute__((ext_vector_type(4)));
+// W streams of a workgroup side by side (W = 1 or 2, chosen per call: one stream per workgroup while that still leaves enough
+// workgroups -- a thread's arithmetic per frame is proportional to W)
+template <int W> struct VadVec { typedef float type __attribute__((ext_vector_type(W))); };
+template <> struct VadVec<1> { struct type { float v; __device__ float &operator[](int) { return v; } __device__ const float &operator[](int) const { return v; } }; };
 
 __device__ __forceinline__ float vad_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-// one row of a gate matrix times [n inputs][VAD_SPW streams] from LDS.  wq: [n / 4][4H][4] -- four consecutive inputs of a
+// one row of a gate matrix times [n inputs][SW streams] from LDS.  wq: [n / 4][4H][4] -- four consecutive inputs of a
 // row side by side, so a lane's load is 16 bytes and a wave's 1 KB of consecutive bytes; n a multiple of 4 (the host pads
 // with zero weights, the kernel keeps the padded inputs at zero).  Fused multiply-adds: this operator's reference is torch.
-__device__ __forceinline__ void vad_dot(vf2 &acc, const float *__restrict__ wq, int H4, int row, const vf2 *x, int n)
+template <int W, typename V>
+__device__ __forceinline__ void vad_dot(V &acc, const float *__restrict__ wq, int H4, int row, const V *x, int n)
 {
     const vf4 *wr = reinterpret_cast<const vf4 *>(wq) + row;
     int q = 0;
@@ -40,40 +44,90 @@ __device__ __forceinline__ void vad_dot(vf2 &acc, const float *__restrict__ wq, 
         for (int u = 0; u < 4; ++u) w[u] = wr[(size_t)(q + u) * H4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const vf4 x01 = *reinterpret_cast<const vf4 *>(x + 4 * (q + u)), x23 = *reinterpret_cast<const vf4 *>(x + 4 * (q + u) + 2);
-            acc.x = __builtin_fmaf(w[u].x, x01.x, acc.x); acc.y = __builtin_fmaf(w[u].x, x01.y, acc.y);
-            acc.x = __builtin_fmaf(w[u].y, x01.z, acc.x); acc.y = __builtin_fmaf(w[u].y, x01.w, acc.y);
-            acc.x = __builtin_fmaf(w[u].z, x23.x, acc.x); acc.y = __builtin_fmaf(w[u].z, x23.y, acc.y);
-            acc.x = __builtin_fmaf(w[u].w, x23.z, acc.x); acc.y = __builtin_fmaf(w[u].w, x23.w, acc.y);
+            const V x0 = x[4 * (q + u)], x1 = x[4 * (q + u) + 1], x2 = x[4 * (q + u) + 2], x3 = x[4 * (q + u) + 3];
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                acc[s] = __builtin_fmaf(w[u].x, x0[s], acc[s]);
+                acc[s] = __builtin_fmaf(w[u].y, x1[s], acc[s]);
+                acc[s] = __builtin_fmaf(w[u].z, x2[s], acc[s]);
+                acc[s] = __builtin_fmaf(w[u].w, x3[s], acc[s]);
+            }
         }
     }
     for (; q < n / 4; ++q) {
         const vf4 w = wr[(size_t)q * H4];
-        const vf4 x01 = *reinterpret_cast<const vf4 *>(x + 4 * q), x23 = *reinterpret_cast<const vf4 *>(x + 4 * q + 2);
-        acc.x = __builtin_fmaf(w.x, x01.x, acc.x); acc.y = __builtin_fmaf(w.x, x01.y, acc.y);
-        acc.x = __builtin_fmaf(w.y, x01.z, acc.x); acc.y = __builtin_fmaf(w.y, x01.w, acc.y);
-        acc.x = __builtin_fmaf(w.z, x23.x, acc.x); acc.y = __builtin_fmaf(w.z, x23.y, acc.y);
-        acc.x = __builtin_fmaf(w.w, x23.z, acc.x); acc.y = __builtin_fmaf(w.w, x23.w, acc.y);
+        const V x0 = x[4 * q], x1 = x[4 * q + 1], x2 = x[4 * q + 2], x3 = x[4 * q + 3];
+#pragma unroll
+        for (int s = 0; s < W; ++s) {
+            acc[s] = __builtin_fmaf(w.x, x0[s], acc[s]);
+            acc[s] = __builtin_fmaf(w.y, x1[s], acc[s]);
+            acc[s] = __builtin_fmaf(w.z, x2[s], acc[s]);
+            acc[s] = __builtin_fmaf(w.w, x3[s], acc[s]);
+        }
     }
 }
 
-template <typename FrameT>
+// the input halves of VAD_TP frames' gate rows at once: one pass over W_ih serves VAD_TP frames; acc[tt] accumulates exactly
+// the terms, in exactly the order, vad_dot would give frame tt
+template <int W, typename V, int XS>
+__device__ __forceinline__ void vad_dot_steps(V (&acc)[VAD_TP], const float *__restrict__ wq, int H4, int row, const V (*x)[XS], int n)
+{
+    const vf4 *wr = reinterpret_cast<const vf4 *>(wq) + row;
+    int q = 0;
+    for (; q + 4 <= n / 4; q += 4) {
+        vf4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = wr[(size_t)(q + u) * H4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int tt = 0; tt < VAD_TP; ++tt) {
+                const V x0 = x[tt][4 * (q + u)], x1 = x[tt][4 * (q + u) + 1], x2 = x[tt][4 * (q + u) + 2], x3 = x[tt][4 * (q + u) + 3];
+#pragma unroll
+                for (int s = 0; s < W; ++s) {
+                    acc[tt][s] = __builtin_fmaf(w[u].x, x0[s], acc[tt][s]);
+                    acc[tt][s] = __builtin_fmaf(w[u].y, x1[s], acc[tt][s]);
+                    acc[tt][s] = __builtin_fmaf(w[u].z, x2[s], acc[tt][s]);
+                    acc[tt][s] = __builtin_fmaf(w[u].w, x3[s], acc[tt][s]);
+                }
+            }
+    }
+    for (; q < n / 4; ++q) {
+        const vf4 w = wr[(size_t)q * H4];
+#pragma unroll
+        for (int tt = 0; tt < VAD_TP; ++tt) {
+            const V x0 = x[tt][4 * q], x1 = x[tt][4 * q + 1], x2 = x[tt][4 * q + 2], x3 = x[tt][4 * q + 3];
+#pragma unroll
+            for (int s = 0; s < W; ++s) {
+                acc[tt][s] = __builtin_fmaf(w.x, x0[s], acc[tt][s]);
+                acc[tt][s] = __builtin_fmaf(w.y, x1[s], acc[tt][s]);
+                acc[tt][s] = __builtin_fmaf(w.z, x2[s], acc[tt][s]);
+                acc[tt][s] = __builtin_fmaf(w.w, x3[s], acc[tt][s]);
+            }
+        }
+    }
+}
+
+template <typename FrameT, int SW>
 __global__ void __launch_bounds__(VAD_THREADS)
 vad_lstm_kernel(DssVadDev v, const FrameT *__restrict__ frames, int W, int *__restrict__ labels, float *__restrict__ logits)
 {
-    __shared__ __attribute__((aligned(16))) vf2 xin[VAD_MAXC];            // [input][stream of this workgroup]
-    __shared__ __attribute__((aligned(16))) vf2 hs[2][VAD_MAXH];          // [layer][unit][stream]; units H .. Hp-1 stay zero
-    __shared__ __attribute__((aligned(16))) vf2 gates[4 * VAD_MAXH];      // [gate row][stream]
-    __shared__ float lg[VAD_SPW][2];
+    typedef typename VadVec<SW>::type V;
+    __shared__ __attribute__((aligned(16))) V xin[VAD_TP][VAD_MAXC];      // [frame of the chunk][input][stream of this workgroup]
+    __shared__ __attribute__((aligned(16))) V h0s[VAD_TP][VAD_MAXH];      // layer 0's h of the chunk's frames (layer 1's inputs)
+    __shared__ __attribute__((aligned(16))) V hs[2][VAD_MAXH];            // [layer][unit][stream]; units H .. Hp-1 stay zero
+    __shared__ __attribute__((aligned(16))) V gates[4 * VAD_MAXH];        // [gate row][stream]
+    __shared__ float lg[SW][2];
     const int tid = threadIdx.x, S = v.S, C = v.C, H = v.H, H4 = 4 * H;
     const int Cp = (C + 3) & ~3, Hp = (H + 3) & ~3;        // the padded input counts the weight copies were built for
-    const int s0 = blockIdx.x * VAD_SPW;
+    const int s0 = blockIdx.x * SW;
     // the (stream, unit) this thread owns in the cell updates
     const int cs = tid / H, cu = tid - cs * H;
-    const bool cell = tid < VAD_SPW * H && s0 + cs < S;
+    const bool cell = tid < SW * H && s0 + cs < S;
     float c0 = 0.f, c1 = 0.f;
-    for (int k = tid; k < 2 * VAD_MAXH * VAD_SPW; k += VAD_THREADS) reinterpret_cast<float *>(hs)[k] = 0.f;
-    for (int k = tid; k < VAD_MAXC * VAD_SPW; k += VAD_THREADS) reinterpret_cast<float *>(xin)[k] = 0.f;
+    for (int k = tid; k < 2 * VAD_MAXH * SW; k += VAD_THREADS) reinterpret_cast<float *>(hs)[k] = 0.f;
+    for (int k = tid; k < VAD_TP * VAD_MAXH * SW; k += VAD_THREADS) reinterpret_cast<float *>(h0s)[k] = 0.f;
+    for (int k = tid; k < VAD_TP * VAD_MAXC * SW; k += VAD_THREADS) reinterpret_cast<float *>(xin)[k] = 0.f;
     __syncthreads();
     if (cell) {
         const size_t o = (size_t)(s0 + cs) * H + cu;
@@ -84,53 +138,70 @@ vad_lstm_kernel(DssVadDev v, const FrameT *__restrict__ frames, int W, int *__re
     const bool rowt = tid < H4;
     const float bias0 = rowt ? v.b0[tid] : 0.f, bias1 = rowt ? v.b1[tid] : 0.f;
 
-    for (int w = 0; w < W; ++w) {
-        // ---- this frame's inputs (units.py:433: frames as float32)
-        for (int idx = tid; idx < C * VAD_SPW; idx += VAD_THREADS) {
-            const int sl = idx / C, k = idx - sl * C;
-            reinterpret_cast<float *>(&xin[k])[sl] = (s0 + sl < S) ? (float)frames[((size_t)(s0 + sl) * W + w) * C + k] : 0.f;
+    // Layer by layer over chunks of VAD_TP frames: a layer's recurrence is serial in time, the input halves of its gates are not --
+    // one pass over W_ih forms them for all frames of the chunk (each gets the same terms in the same order as a frame on its
+    // own), and a step then adds only W_hh h.  Layer 1's inputs are layer 0's h of the chunk's frames (h0s).
+    for (int w0 = 0; w0 < W; w0 += VAD_TP) {
+        const int nst = min(VAD_TP, W - w0);
+        for (int idx = tid; idx < nst * C * SW; idx += VAD_THREADS) {       // the chunk's inputs (units.py:433: frames as float32)
+            const int tt = idx / (C * SW), rem = idx - tt * (C * SW);
+            const int sl = rem / C, k = rem - sl * C;
+            reinterpret_cast<float *>(&xin[tt][k])[sl] = (s0 + sl < S) ? (float)frames[((size_t)(s0 + sl) * W + w0 + tt) * C + k] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int layer = 0; layer < 2; ++layer) {
-            // ---- gate pre-activations of this layer: W_ih x + W_hh h + (b_ih + b_hh)
-            if (rowt) {
-                vf2 acc = {0.f, 0.f};
-                if (layer == 0) {
-                    vad_dot(acc, v.wT0, H4, tid, xin, Cp);
-                    vad_dot(acc, v.wT0 + (size_t)Cp * H4, H4, tid, hs[0], Hp);
-                    acc += bias0;
-                } else {
-                    vad_dot(acc, v.wT1, H4, tid, hs[0], Hp);                     // input = layer 0's new h
-                    vad_dot(acc, v.wT1 + (size_t)Hp * H4, H4, tid, hs[1], Hp);
-                    acc += bias1;
+            V pre[VAD_TP];
+#pragma unroll
+            for (int tt = 0; tt < VAD_TP; ++tt)
+#pragma unroll
+                for (int s = 0; s < SW; ++s) pre[tt][s] = 0.f;
+            if (rowt) {                                    // (frames beyond nst: stale inputs, never used)
+                if (layer == 0) vad_dot_steps<SW, V, VAD_MAXC>(pre, v.wT0, H4, tid, xin, Cp);
+                else vad_dot_steps<SW, V, VAD_MAXH>(pre, v.wT1, H4, tid, h0s, Hp);
+            }
+#pragma unroll
+            for (int tt = 0; tt < VAD_TP; ++tt) {
+                if (tt >= nst) break;
+                // ---- gate pre-activations of this layer and frame: W_ih x + W_hh h + (b_ih + b_hh)
+                if (rowt) {
+                    V acc = pre[tt];
+                    if (layer == 0) vad_dot<SW, V>(acc, v.wT0 + (size_t)Cp * H4, H4, tid, hs[0], Hp);
+                    else vad_dot<SW, V>(acc, v.wT1 + (size_t)Hp * H4, H4, tid, hs[1], Hp);
+#pragma unroll
+                    for (int s = 0; s < SW; ++s) acc[s] += layer == 0 ? bias0 : bias1;
+                    gates[tid] = acc;
                 }
-                gates[tid] = acc;
+                __syncthreads();
+                // ---- cell update of (stream cs, unit cu): c' = f c + i g, h' = o tanh(c')
+                if (tid < SW * H) {
+                    const float gi = reinterpret_cast<const float *>(&gates[cu])[cs];
+                    const float gf = reinterpret_cast<const float *>(&gates[H + cu])[cs];
+                    const float gg = reinterpret_cast<const float *>(&gates[2 * H + cu])[cs];
+                    const float go = reinterpret_cast<const float *>(&gates[3 * H + cu])[cs];
+                    float &c = layer == 0 ? c0 : c1;
+                    c = vad_sigmoid(gf) * c + vad_sigmoid(gi) * tanhf(gg);
+                    const float h = vad_sigmoid(go) * tanhf(c);
+                    reinterpret_cast<float *>(&hs[layer][cu])[cs] = h;
+                    if (layer == 0) reinterpret_cast<float *>(&h0s[tt][cu])[cs] = h;
+                }
+                __syncthreads();
+                if (layer == 1) {
+                    // ---- classifier (models.py:20,32) and the raw label (units.py:434: argmax, the first maximum wins)
+                    const int w = w0 + tt;
+                    if (tid < SW * 2) {
+                        const int sl = tid >> 1, cls = tid & 1;
+                        float a = 0.f;
+                        for (int k = 0; k < H; ++k) a = __builtin_fmaf(v.wc[cls * H + k], reinterpret_cast<const float *>(&hs[1][k])[sl], a);
+                        a += v.bc[cls];
+                        lg[sl][cls] = a;
+                        if (logits && s0 + sl < S) logits[((size_t)(s0 + sl) * W + w) * 2 + cls] = a;
+                    }
+                    __syncthreads();
+                    if (tid < SW && s0 + tid < S) labels[(size_t)(s0 + tid) * W + w] = lg[tid][1] > lg[tid][0] ? 1 : 0;
+                }
             }
-            __syncthreads();
-            // ---- cell update of (stream cs, unit cu): c' = f c + i g, h' = o tanh(c')
-            if (tid < VAD_SPW * H) {
-                const float gi = reinterpret_cast<const float *>(&gates[cu])[cs];
-                const float gf = reinterpret_cast<const float *>(&gates[H + cu])[cs];
-                const float gg = reinterpret_cast<const float *>(&gates[2 * H + cu])[cs];
-                const float go = reinterpret_cast<const float *>(&gates[3 * H + cu])[cs];
-                float &c = layer == 0 ? c0 : c1;
-                c = vad_sigmoid(gf) * c + vad_sigmoid(gi) * tanhf(gg);
-                reinterpret_cast<float *>(&hs[layer][cu])[cs] = vad_sigmoid(go) * tanhf(c);
-            }
-            __syncthreads();
         }
-        // ---- classifier (models.py:20,32) and the raw label (units.py:434: argmax, the first maximum wins)
-        if (tid < VAD_SPW * 2) {
-            const int sl = tid >> 1, cls = tid & 1;
-            float a = 0.f;
-            for (int k = 0; k < H; ++k) a = __builtin_fmaf(v.wc[cls * H + k], reinterpret_cast<const float *>(&hs[1][k])[sl], a);
-            a += v.bc[cls];
-            lg[sl][cls] = a;
-            if (logits && s0 + sl < S) logits[((size_t)(s0 + sl) * W + w) * 2 + cls] = a;
-        }
-        __syncthreads();
-        if (tid < VAD_SPW && s0 + tid < S) labels[(size_t)(s0 + tid) * W + w] = lg[tid][1] > lg[tid][0] ? 1 : 0;
     }
     if (cell) {
         const size_t o = (size_t)(s0 + cs) * H + cu;
@@ -143,13 +214,16 @@ vad_lstm_kernel(DssVadDev v, const FrameT *__restrict__ frames, int W, int *__re
 
 int dss_launch_vad(const DssVadDev &v, const void *d_frames, int frames_f64, int W, int *d_labels, float *d_logits, hipStream_t st)
 {
-    if (v.H < 1 || v.H > VAD_MAXH || 4 * v.H > VAD_THREADS || v.C < 1 || v.C > VAD_MAXC || VAD_SPW * v.H > VAD_THREADS) {
+    if (v.H < 1 || v.H > VAD_MAXH || 4 * v.H > VAD_THREADS || v.C < 1 || v.C > VAD_MAXC || 2 * v.H > VAD_THREADS) {
         dss_set_error("VAD kernel: hidden size %d / %d inputs out of range (<= %d / <= %d)", v.H, v.C, VAD_MAXH, VAD_MAXC);
         return DSS_EINVAL;
     }
-    const dim3 grid((v.S + VAD_SPW - 1) / VAD_SPW), block(VAD_THREADS);
-    if (frames_f64) hipLaunchKernelGGL(vad_lstm_kernel<double>, grid, block, 0, st, v, (const double *)d_frames, W, d_labels, d_logits);
-    else hipLaunchKernelGGL(vad_lstm_kernel<float>, grid, block, 0, st, v, (const float *)d_frames, W, d_labels, d_logits);
+    const dim3 block(VAD_THREADS);
+    const int Wsel = v.S <= 256 ? 1 : 2;         // one stream per workgroup while that leaves no CU without work for long
+#define VAD_LAUNCH(FT, WV) hipLaunchKernelGGL((vad_lstm_kernel<FT, WV>), dim3((v.S + WV - 1) / WV), block, 0, st, v, (const FT *)d_frames, W, d_labels, d_logits)
+    if (frames_f64) { if (Wsel == 1) VAD_LAUNCH(double, 1); else VAD_LAUNCH(double, 2); }
+    else { if (Wsel == 1) VAD_LAUNCH(float, 1); else VAD_LAUNCH(float, 2); }
+#undef VAD_LAUNCH
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }
