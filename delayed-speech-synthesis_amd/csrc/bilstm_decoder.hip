@@ -19,8 +19,8 @@
 #include "dss_common.h"
 
 #define DEC_THREADS 512           // >= 4 * H and >= W * H
-#define DEC_MAXH 128              // (a multiple of 4)
-#define DEC_MAXC 256              // inputs of a layer: n_inputs for layer 0, 2H above it
+#define DEC_MAXH DSS_DEC_MAXH              // (a multiple of 4)
+#define DEC_MAXC DSS_DEC_MAXC              // inputs of a layer: n_inputs for layer 0, 2H above it
 #define DEC_TP 4                  // steps whose input halves (W_ih x) are formed in one pass over W_ih
 
 typedef float df4 __attribute__((ext_vector_type(4)));
@@ -74,11 +74,14 @@ __device__ __forceinline__ void dec_dot_steps(V (&acc)[DEC_TP], const float *__r
 }
 
 // One layer, both directions (blockIdx.y): in (S, T, Cin) -> out (S, T, 2H), forward h in [0, H), backward in [H, 2H).
+// Ragged form (segments of different lengths in one call, dss_dec_forward_rows_dev): stream s has counts[s] <= T frames (NULL:
+// T) -- its backward direction starts at its OWN last frame, and nothing is computed or written beyond it -- and its input
+// frames are row in_row[s] (NULL: s) of a buffer with Tin frames per row (a pool of segment buffers).
 template <typename InT, int W>
 __global__ void __launch_bounds__(DEC_THREADS)
 bilstm_layer_kernel(const InT *__restrict__ in, int S, int T, int Cin, int H, const float *__restrict__ wT_f,
                     const float *__restrict__ wT_b, const float *__restrict__ b_f, const float *__restrict__ b_b,
-                    float *__restrict__ out)
+                    float *__restrict__ out, const int *__restrict__ counts, const int *__restrict__ in_row, int Tin)
 {
     typedef typename DecVec<W>::type V;
     __shared__ __attribute__((aligned(16))) V xin[DEC_TP][DEC_MAXC];      // [step of the chunk][input][stream of this workgroup]
@@ -90,6 +93,13 @@ bilstm_layer_kernel(const InT *__restrict__ in, int S, int T, int Cin, int H, co
     const float *wT = dir ? wT_b : wT_f;
     const int cs = tid / H, cu = tid - cs * H;             // the (stream, unit) this thread owns in the cell updates
     const bool cell = tid < W * H && s0 + cs < S;
+    const int Tc = cell ? (counts ? min(counts[s0 + cs], T) : T) : 0;      // frames of the stream this thread's cell belongs to
+    __shared__ int Tsh[W], Rsh[W];                         // per stream of this workgroup: frames, input row
+    if (tid < W) {
+        const bool live = s0 + tid < S;
+        Tsh[tid] = live ? (counts ? min(counts[s0 + tid], T) : T) : 0;
+        Rsh[tid] = live ? (in_row ? in_row[s0 + tid] : s0 + tid) : 0;
+    }
     float c = 0.f;                                         // create_new_initial_state: zeros (models.py:22-24)
     for (int k = tid; k < DEC_MAXH * W; k += DEC_THREADS) reinterpret_cast<float *>(hs)[k] = 0.f;
     for (int k = tid; k < DEC_TP * DEC_MAXC * W; k += DEC_THREADS) reinterpret_cast<float *>(xin)[k] = 0.f;
@@ -104,15 +114,19 @@ bilstm_layer_kernel(const InT *__restrict__ in, int S, int T, int Cin, int H, co
         for (int q = 0; q < DEC_MAXH / 4; ++q) whh[q] = (rowt && 4 * q < Hp) ? wr[(size_t)q * H4] : (df4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
+    int Tw = 0;                                            // the longest of this workgroup's streams
+#pragma unroll
+    for (int sl = 0; sl < W; ++sl) Tw = max(Tw, Tsh[sl]);
     // The recurrence is serial in time, the input halves of the gates are not: per chunk of DEC_TP steps one pass over W_ih forms
     // them for all its steps (each gets the same terms in the same order as a step on its own), and a step then adds only W_hh h.
-    for (int step0 = 0; step0 < T; step0 += DEC_TP) {
-        const int nst = min(DEC_TP, T - step0);
+    for (int step0 = 0; step0 < Tw; step0 += DEC_TP) {
+        const int nst = min(DEC_TP, Tw - step0);
         for (int idx = tid; idx < nst * Cin * W; idx += DEC_THREADS) {
             const int tt = idx / (Cin * W), rem = idx - tt * (Cin * W);
             const int sl = rem / Cin, k = rem - sl * Cin;
-            const int t = dir ? T - 1 - (step0 + tt) : step0 + tt;
-            reinterpret_cast<float *>(&xin[tt][k])[sl] = (s0 + sl < S) ? (float)in[((size_t)(s0 + sl) * T + t) * Cin + k] : 0.f;
+            const int Ts = Tsh[sl], step = step0 + tt;
+            const int t = dir ? Ts - 1 - step : step;
+            reinterpret_cast<float *>(&xin[tt][k])[sl] = step < Ts ? (float)in[((size_t)Rsh[sl] * Tin + t) * Cin + k] : 0.f;
         }
         __syncthreads();
         V pre[DEC_TP];
@@ -124,7 +138,7 @@ bilstm_layer_kernel(const InT *__restrict__ in, int S, int T, int Cin, int H, co
 #pragma unroll
         for (int tt = 0; tt < DEC_TP; ++tt) {
             if (tt >= nst) break;
-            const int t = dir ? T - 1 - (step0 + tt) : step0 + tt;
+            const int step = step0 + tt;
             if (rowt) {                                    // gate pre-activations: W_ih x + W_hh h + (b_ih + b_hh)
                 V acc = pre[tt];
 #pragma unroll
@@ -144,7 +158,7 @@ bilstm_layer_kernel(const InT *__restrict__ in, int S, int T, int Cin, int H, co
                 gates[tid] = acc;
             }
             __syncthreads();
-            if (tid < W * H) {                             // cell update of (stream cs, unit cu): c' = f c + i g, h' = o tanh(c')
+            if (tid < W * H && step < Tc) {                // cell update of (stream cs, unit cu): c' = f c + i g, h' = o tanh(c')
                 const float gi = reinterpret_cast<const float *>(&gates[cu])[cs];
                 const float gf = reinterpret_cast<const float *>(&gates[H + cu])[cs];
                 const float gg = reinterpret_cast<const float *>(&gates[2 * H + cu])[cs];
@@ -152,7 +166,7 @@ bilstm_layer_kernel(const InT *__restrict__ in, int S, int T, int Cin, int H, co
                 c = dec_sigmoid(gf) * c + dec_sigmoid(gi) * tanhf(gg);
                 const float h = dec_sigmoid(go) * tanhf(c);
                 reinterpret_cast<float *>(&hs[cu])[cs] = h;
-                if (cell) out[((size_t)(s0 + cs) * T + t) * (2 * H) + dir * H + cu] = h;
+                out[((size_t)(s0 + cs) * T + (dir ? Tc - 1 - step : step)) * (2 * H) + dir * H + cu] = h;
             }
             __syncthreads();
         }
@@ -165,21 +179,23 @@ bilstm_layer_kernel(const InT *__restrict__ in, int S, int T, int Cin, int H, co
 #define DEC_RROWS 8
 __global__ void __launch_bounds__(256)
 dec_regress_kernel(const float *__restrict__ top, long rows, int K, int O, const float *__restrict__ w, const float *__restrict__ b,
-                   float *__restrict__ feats)
+                   float *__restrict__ feats, const int *__restrict__ counts, int T)
 {
     extern __shared__ __attribute__((aligned(16))) float rs[];             // [O][K + 1] weights, then [DEC_RROWS][K] inputs
     float *ws = rs, *xs = rs + (size_t)O * (K + 1);
     const int tid = threadIdx.x;
     const long r0 = (long)blockIdx.x * DEC_RROWS;
     for (int k = tid; k < O * K; k += 256) { const int o = k / K, j = k - o * K; ws[o * (K + 1) + j] = w[k]; }
+    // ragged calls: row r = (stream r / T, frame r % T) exists only below its stream's frame count
+    auto live = [&](long r) { return r < rows && (!counts || (int)(r % T) < counts[r / T]); };
     for (int k = tid; k < DEC_RROWS * K; k += 256) {
         const long r = r0 + k / K;
-        xs[k] = r < rows ? top[r * K + (k % K)] : 0.f;
+        xs[k] = live(r) ? top[r * K + (k % K)] : 0.f;
     }
     __syncthreads();
     for (int idx = tid; idx < DEC_RROWS * O; idx += 256) {
         const int rr = idx / O, o = idx - rr * O;
-        if (r0 + rr >= rows) continue;
+        if (!live(r0 + rr)) continue;
         const float *x = xs + rr * K, *wr = ws + o * (K + 1);
         float a = 0.f;
         for (int k = 0; k < K; ++k) a = __builtin_fmaf(wr[k], x[k], a);
@@ -187,8 +203,10 @@ dec_regress_kernel(const float *__restrict__ top, long rows, int K, int O, const
     }
 }
 
-int dss_launch_decoder(const DssDecDev &d, const void *d_frames, int frames_f64, int S, int T, float *d_feats, hipStream_t st)
+int dss_launch_decoder(const DssDecDev &d, const void *d_frames, int frames_f64, int S, int T, float *d_feats,
+                       const int *d_counts, const int *d_in_row, int Tin, hipStream_t st)
 {
+    if (Tin <= 0) Tin = T;                                 // plain calls: the input is (S, T, C)
     if (d.H < 1 || d.H > DEC_MAXH || 4 * d.H > DEC_THREADS || d.C < 1 || d.C > DEC_MAXC || 2 * d.H > DEC_MAXC) {
         dss_set_error("decoder kernel: hidden size %d / %d inputs out of range (<= %d / <= %d)", d.H, d.C, DEC_MAXH, DEC_MAXC);
         return DSS_EINVAL;
@@ -204,7 +222,8 @@ int dss_launch_decoder(const DssDecDev &d, const void *d_frames, int frames_f64,
     const dim3 block(DEC_THREADS);
 #define DEC_LAUNCH(INT, WV, IN, CIN, L, OUT)                                                                                   \
     hipLaunchKernelGGL((bilstm_layer_kernel<INT, WV>), dim3((S + WV - 1) / WV, 2), block, 0, st, (const INT *)(IN), S, T, CIN, d.H,  \
-                       d.wT[L][0], d.wT[L][1], d.b[L][0], d.b[L][1], OUT)
+                       d.wT[L][0], d.wT[L][1], d.b[L][0], d.b[L][1], OUT, d_counts, (L) == 0 ? d_in_row : (const int *)nullptr,   \
+                       (L) == 0 ? Tin : T)
 #define DEC_LAUNCH_W(INT, IN, CIN, L, OUT)                                                                                      \
     do {                                                                                                                        \
         if (Wsel == 1) DEC_LAUNCH(INT, 1, IN, CIN, L, OUT);                                                                     \
@@ -219,7 +238,7 @@ int dss_launch_decoder(const DssDecDev &d, const void *d_frames, int frames_f64,
     const long rows = (long)S * T;
     const size_t rlds = ((size_t)d.O * (2 * d.H + 1) + (size_t)DEC_RROWS * 2 * d.H) * sizeof(float);
     hipLaunchKernelGGL(dec_regress_kernel, dim3((unsigned)((rows + DEC_RROWS - 1) / DEC_RROWS)), dim3(256), rlds, st, d.top, rows, 2 * d.H,
-                       d.O, d.wr, d.br, d_feats);
+                       d.O, d.wr, d.br, d_feats, d_counts, T);
     DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }

@@ -15,7 +15,7 @@
 #include <mutex>
 #include <vector>
 
-#include "dss_common.h"
+#include "dss_host.h"
 
 // ------------------------------------------------------------------------------------------------------
 // errors / device
@@ -36,7 +36,7 @@ static thread_local int g_device = -1;
 // while upload_model() runs: the list every dev_upload() allocation is recorded in (so a model can be freed)
 static thread_local std::vector<std::pair<int, void *>> *g_track = nullptr;
 
-static int ensure_device()
+int dss_ensure_device(void)
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -72,7 +72,7 @@ extern "C" int dss_set_device(int device)
 
 extern "C" int dss_current_device(void)
 {
-    if (ensure_device()) return DSS_ENODEV;
+    if (dss_ensure_device()) return DSS_ENODEV;
     return g_device;
 }
 
@@ -634,7 +634,7 @@ static int load_blob_locked(const void *blob, size_t len);
 
 static int get_model(HostModel **out_hm, const DssModelDev **out, bool acquire)
 {
-    int rc = ensure_device();
+    int rc = dss_ensure_device();
     if (rc) return rc;
     std::unique_lock<std::mutex> lk(g_model_mu);
     if (!g_model) {
@@ -680,41 +680,28 @@ struct dss_lpcnet_batch {
     int force_utts = 0, force_frames = 0;   // shape force_exc / trace_logits were sized for (dss_lpcnet_batch_force_excitation)
     int trace = 0, timing = 0;
     int pair = 0;                 // 0 auto, -1 never, 2 always: two utterances per workgroup (dss_lpcnet_batch_set_multi)
+    int max_rows = 0;             // rows one call may carry (= scratch rows); d.max_utts = decoder slots (a lane: its parent's)
+    dss_lpcnet_batch *parent = nullptr;   // a lane (dss_lpcnet_batch_create_lane): decoder state aliases the parent's arrays
+    int lanes = 0;                // live lanes of this (parent) batch
+    bool dead = false;            // destroyed by the caller while lanes were alive: freed with the last lane
     float *d_feat = nullptr;      // staging for the host-buffer entry point
     short *d_pcm = nullptr;
-    int *d_slots = nullptr;       // [max_utts] slot list of a ragged call
-    int *d_counts = nullptr;      // [max_utts] frame counts of a ragged call
-    int *d_order = nullptr;       // [max_utts] dispatch order of a ragged call: rows by decreasing frame count
-    std::vector<int> h_order;     //   its host copy (kept until the async copy has been issued from it)
+    int *d_slots = nullptr;       // [max_rows] slot list of a ragged call
+    int *d_counts = nullptr;      // [max_rows] frame counts of a ragged call
+    int *d_order = nullptr;       // [max_rows] dispatch order of a ragged call: rows by decreasing frame count
+    DssPinnedRing meta;           // pinned staging of those three lists ([3][max_rows] ints per slot of the ring)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     double ms_sum[2] = {0, 0};
     int ms_n = 0;
 };
 
-extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frames)
+// per-call scratch (rows x frames), the staging buffers and the events: what a plain batch and a lane both own
+static int batch_alloc_scratch(dss_lpcnet_batch *b, int max_rows, int max_frames)
 {
-    if (max_utts <= 0 || max_frames <= 0) { dss_set_error("batch dims must be positive"); return nullptr; }
-    HostModel *hm; const DssModelDev *m;
-    if (get_model(&hm, &m, true)) return nullptr;            // holds one reference from here on (dropped by destroy)
-    dss_lpcnet_batch *b = new dss_lpcnet_batch;
-    memset(&b->d, 0, sizeof(b->d));
-    b->device = g_device;
-    b->host_model = hm;
-    b->model = m;
     DssBatchDev &d = b->d;
-    d.max_utts = max_utts; d.max_frames = max_frames;
-    const size_t B = max_utts, F = max_frames;
+    b->max_rows = max_rows; d.max_frames = max_frames;
+    const size_t B = max_rows, F = max_frames;
     int rc = 0;
-    rc |= dev_alloc<float>(B * DSS_GRU_A, &d.gru_a_state);
-    rc |= dev_alloc<float>(B * DSS_GRU_B, &d.gru_b_state);
-    rc |= dev_alloc<float>(B * 16, &d.last_sig);
-    rc |= dev_alloc<int>(B, &d.last_exc);
-    rc |= dev_alloc<float>(B, &d.deemph);
-    rc |= dev_alloc<uint32_t>(B * 4, &d.rng);
-    rc |= dev_alloc<int>(B, &d.frame_count);
-    rc |= dev_alloc<float>(B * 2 * 84, &d.conv1_mem);
-    rc |= dev_alloc<float>(B * 2 * 128, &d.conv2_mem);
-    rc |= dev_alloc<float>(B * 2 * 16, &d.old_lpc);
     rc |= dev_alloc<float>(B * (F + 2) * 84, &d.in_buf);
     rc |= dev_alloc<float>(B * (F + 2) * 128, &d.c1_buf);
     rc |= dev_alloc<float>(B * F * 128, &d.c2_buf);
@@ -728,7 +715,36 @@ extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frame
     rc |= dev_alloc<int>(B, &b->d_slots);
     rc |= dev_alloc<int>(B, &b->d_counts);
     rc |= dev_alloc<int>(B, &b->d_order);
+    rc |= b->meta.init(3 * B);
     for (int i = 0; i < 3; ++i) rc |= (hipEventCreate(&b->ev[i]) != hipSuccess);
+    return rc;
+}
+
+extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frames)
+{
+    if (max_utts <= 0 || max_frames <= 0) { dss_set_error("batch dims must be positive"); return nullptr; }
+    HostModel *hm; const DssModelDev *m;
+    if (get_model(&hm, &m, true)) return nullptr;            // holds one reference from here on (dropped by destroy)
+    dss_lpcnet_batch *b = new dss_lpcnet_batch;
+    memset(&b->d, 0, sizeof(b->d));
+    b->device = g_device;
+    b->host_model = hm;
+    b->model = m;
+    DssBatchDev &d = b->d;
+    d.max_utts = max_utts;
+    const size_t B = max_utts;
+    int rc = 0;
+    rc |= dev_alloc<float>(B * DSS_GRU_A, &d.gru_a_state);
+    rc |= dev_alloc<float>(B * DSS_GRU_B, &d.gru_b_state);
+    rc |= dev_alloc<float>(B * 16, &d.last_sig);
+    rc |= dev_alloc<int>(B, &d.last_exc);
+    rc |= dev_alloc<float>(B, &d.deemph);
+    rc |= dev_alloc<uint32_t>(B * 4, &d.rng);
+    rc |= dev_alloc<int>(B, &d.frame_count);
+    rc |= dev_alloc<float>(B * 2 * 84, &d.conv1_mem);
+    rc |= dev_alloc<float>(B * 2 * 128, &d.conv2_mem);
+    rc |= dev_alloc<float>(B * 2 * 16, &d.old_lpc);
+    rc |= batch_alloc_scratch(b, max_utts, max_frames);
     if (rc) {
         dss_set_error("device allocation failed for batch %d x %d", max_utts, max_frames);
         dss_lpcnet_batch_destroy(b);
@@ -738,18 +754,66 @@ extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frame
     return b;
 }
 
+// A lane: a second launch context on the decoder states of `parent`.  It owns scratch for max_rows x max_frames and nothing
+// else; its rows name the parent's slots (ragged calls with a slot list).  Lanes exist so that calls touching DIFFERENT slots
+// can be in flight on different streams at once (the asynchronous segment synthesis of the gated streaming mode).
+extern "C" dss_lpcnet_batch *dss_lpcnet_batch_create_lane(dss_lpcnet_batch *parent, int max_rows, int max_frames)
+{
+    if (!parent || parent->parent || parent->dead || max_rows <= 0 || max_frames <= 0) {
+        dss_set_error("dss_lpcnet_batch_create_lane: needs a live batch that is not itself a lane, and positive dims");
+        return nullptr;
+    }
+    if (hipSetDevice(parent->device) != hipSuccess) { dss_set_error("hipSetDevice failed"); return nullptr; }
+    dss_lpcnet_batch *b = new dss_lpcnet_batch;
+    b->d = parent->d;                              // the state arrays (and max_utts = the slot count) are the parent's
+    DssBatchDev &d = b->d;
+    d.in_buf = d.c1_buf = d.c2_buf = d.d1_buf = d.cond_buf = d.lpc_buf = d.frame_out = nullptr;
+    d.fc0 = nullptr; d.slot_of = d.count_of = d.row_of = nullptr; d.utt0 = 0;
+    d.trace_exc = d.trace_pcm = d.trace_logits = nullptr; d.force_exc = nullptr;
+    b->device = parent->device;
+    b->host_model = parent->host_model;
+    b->model = parent->model;
+    b->pair = parent->pair;
+    b->parent = parent;
+    parent->lanes += 1;
+    if (batch_alloc_scratch(b, max_rows, max_frames)) {
+        dss_set_error("device allocation failed for lane %d x %d", max_rows, max_frames);
+        dss_lpcnet_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+static void batch_free(dss_lpcnet_batch *b)
+{
+    DssBatchDev &d = b->d;
+    if (!b->parent) {
+        void *state[] = {d.gru_a_state, d.gru_b_state, d.last_sig, d.last_exc, d.deemph, d.rng, d.frame_count, d.conv1_mem,
+                         d.conv2_mem, d.old_lpc};
+        for (void *p : state) if (p) hipFree(p);
+    }
+    void *ptrs[] = {d.in_buf, d.c1_buf, d.c2_buf, d.d1_buf, d.cond_buf, d.lpc_buf, d.frame_out,
+                    d.fc0, d.trace_exc, d.trace_pcm, d.trace_logits, (void *)d.force_exc, b->d_feat, b->d_pcm, b->d_slots, b->d_counts, b->d_order};
+    for (void *p : ptrs) if (p) hipFree(p);
+    b->meta.destroy();
+    for (int i = 0; i < 3; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
+    if (!b->parent) release_model(b->host_model);
+    delete b;
+}
+
 extern "C" void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b)
 {
     if (!b) return;
     hipSetDevice(b->device);
-    DssBatchDev &d = b->d;
-    void *ptrs[] = {d.gru_a_state, d.gru_b_state, d.last_sig, d.last_exc, d.deemph, d.rng, d.frame_count, d.conv1_mem,
-                    d.conv2_mem, d.old_lpc, d.in_buf, d.c1_buf, d.c2_buf, d.d1_buf, d.cond_buf, d.lpc_buf, d.frame_out,
-                    d.fc0, d.trace_exc, d.trace_pcm, d.trace_logits, (void *)d.force_exc, b->d_feat, b->d_pcm, b->d_slots, b->d_counts, b->d_order};
-    for (void *p : ptrs) if (p) hipFree(p);
-    for (int i = 0; i < 3; ++i) if (b->ev[i]) hipEventDestroy(b->ev[i]);
-    release_model(b->host_model);
-    delete b;
+    hipDeviceSynchronize();                        // nothing of this object may still be in flight on any stream
+    if (b->parent) {
+        dss_lpcnet_batch *p = b->parent;
+        batch_free(b);
+        if (--p->lanes == 0 && p->dead) batch_free(p);
+        return;
+    }
+    if (b->lanes > 0) { b->dead = true; return; }  // its lanes still run on its state: freed with the last of them
+    batch_free(b);
 }
 
 extern "C" int dss_lpcnet_batch_reset(dss_lpcnet_batch *b, int utt)
@@ -774,7 +838,7 @@ extern "C" int dss_lpcnet_batch_enable_trace(dss_lpcnet_batch *b, int on)
     if (!b) return DSS_EINVAL;
     DSS_HIP_CHECK(hipSetDevice(b->device));
     if (on && !b->d.trace_exc) {
-        const size_t n = (size_t)b->d.max_utts * b->d.max_frames * DSS_FRAME_SIZE;
+        const size_t n = (size_t)b->max_rows * b->d.max_frames * DSS_FRAME_SIZE;
         int rc = dev_alloc<float>(n, &b->d.trace_exc);
         rc |= dev_alloc<float>(n, &b->d.trace_pcm);
         if (rc) return DSS_ENOMEM;
@@ -794,7 +858,7 @@ extern "C" int dss_lpcnet_batch_force_excitation(dss_lpcnet_batch *b, const unsi
         b->force_utts = b->force_frames = 0;
         return DSS_OK;
     }
-    if (n_utts <= 0 || n_utts > b->d.max_utts || n_frames <= 0 || n_frames > b->d.max_frames) {
+    if (n_utts <= 0 || n_utts > b->max_rows || n_frames <= 0 || n_frames > b->d.max_frames) {
         dss_set_error("forced excitation shape out of range"); return DSS_EINVAL;
     }
     if (!b->trace) { dss_set_error("teacher forcing needs dss_lpcnet_batch_enable_trace(b, 1 or 17) first"); return DSS_EINVAL; }
@@ -862,8 +926,9 @@ extern "C" double dss_lpcnet_batch_kernel_ms(dss_lpcnet_batch *b, int which)
 
 static int check_batch_shape(dss_lpcnet_batch *b, int n_utts, int n_frames, int feat_stride)
 {
-    if (n_utts <= 0 || n_utts > b->d.max_utts || n_frames <= 0 || n_frames > b->d.max_frames || feat_stride < DSS_NB_FEATURES) {
-        dss_set_error("shape out of range: %d utts (max %d), %d frames (max %d), stride %d", n_utts, b->d.max_utts, n_frames,
+    if (b->dead) { dss_set_error("this batch was destroyed (only its lanes are alive)"); return DSS_EINVAL; }
+    if (n_utts <= 0 || n_utts > b->max_rows || n_frames <= 0 || n_frames > b->d.max_frames || feat_stride < DSS_NB_FEATURES) {
+        dss_set_error("shape out of range: %d utts (max %d), %d frames (max %d), stride %d", n_utts, b->max_rows, n_frames,
                       b->d.max_frames, feat_stride);
         return DSS_EINVAL;
     }
@@ -913,7 +978,8 @@ extern "C" int dss_lpcnet_batch_synthesize_dev(dss_lpcnet_batch *b, const float 
     return run_batch(b, d_features, n_utts, n_frames, feat_stride, d_pcm, (hipStream_t)hip_stream);
 }
 
-// Validate and upload the slot list / frame counts of a ragged call (either may be NULL).
+// Validate and upload the slot list / frame counts of a ragged call (either may be NULL).  The lists go through a pinned
+// ring (dss_host.h): the upload neither waits for what is queued on `s` nor can a later call overwrite it before it has run.
 static int stage_ragged(dss_lpcnet_batch *b, const int *slots, const int *counts, int n_utts, int n_frames, hipStream_t s)
 {
     b->d.slot_of = nullptr; b->d.count_of = nullptr; b->d.row_of = nullptr;
@@ -924,23 +990,34 @@ static int stage_ragged(dss_lpcnet_batch *b, const int *slots, const int *counts
             if (seen[slots[i]]) { dss_set_error("row %d: slot %d appears twice in one call (a decoder is sequential)", i, slots[i]); return DSS_EINVAL; }
             seen[slots[i]] = 1;
         }
-        DSS_HIP_CHECK(hipMemcpyAsync(b->d_slots, slots, sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
+    } else if (n_utts > b->d.max_utts) {
+        dss_set_error("%d rows without a slot list, %d decoder slots", n_utts, b->d.max_utts); return DSS_EINVAL;
+    }
+    if (counts)
+        for (int i = 0; i < n_utts; ++i)
+            if (counts[i] < 0 || counts[i] > n_frames) { dss_set_error("row %d: %d frames outside [0, %d]", i, counts[i], n_frames); return DSS_EINVAL; }
+    if (!slots && !counts) return DSS_OK;
+    int *h = b->meta.acquire();
+    if (!h) { dss_set_error("pinned staging ring failed"); return DSS_ENODEV; }
+    const size_t R = (size_t)b->max_rows;
+    if (slots) {
+        memcpy(h, slots, sizeof(int) * n_utts);
+        DSS_HIP_CHECK(hipMemcpyAsync(b->d_slots, h, sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
         b->d.slot_of = b->d_slots;
     }
     if (counts) {
-        for (int i = 0; i < n_utts; ++i)
-            if (counts[i] < 0 || counts[i] > n_frames) { dss_set_error("row %d: %d frames outside [0, %d]", i, counts[i], n_frames); return DSS_EINVAL; }
-        DSS_HIP_CHECK(hipMemcpyAsync(b->d_counts, counts, sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
+        memcpy(h + R, counts, sizeof(int) * n_utts);
+        DSS_HIP_CHECK(hipMemcpyAsync(b->d_counts, h + R, sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
         b->d.count_of = b->d_counts;
         // Dispatch order: workgroups start in grid order, so the longest rows go first whatever order the caller used
         // (and the pair kernel's two rows of a workgroup are neighbours in length).  Results do not depend on it.
-        b->h_order.resize((size_t)n_utts);
-        for (int i = 0; i < n_utts; ++i) b->h_order[i] = i;
-        std::stable_sort(b->h_order.begin(), b->h_order.end(), [&](int x, int y) { return counts[x] > counts[y]; });
-        DSS_HIP_CHECK(hipMemcpyAsync(b->d_order, b->h_order.data(), sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
+        int *order = h + 2 * R;
+        for (int i = 0; i < n_utts; ++i) order[i] = i;
+        std::stable_sort(order, order + n_utts, [&](int x, int y) { return counts[x] > counts[y]; });
+        DSS_HIP_CHECK(hipMemcpyAsync(b->d_order, order, sizeof(int) * n_utts, hipMemcpyHostToDevice, s));
         b->d.row_of = b->d_order;
     }
-    return DSS_OK;
+    return b->meta.commit(s);
 }
 
 extern "C" int dss_lpcnet_batch_synthesize_ragged_dev(dss_lpcnet_batch *b, const float *d_features, const int *slots,
@@ -1276,7 +1353,7 @@ extern "C" int dss_selftest_fast_layout(const void *blob, size_t len, int *info)
 extern "C" int dss_selftest_exp10(const float *x, const float *comp, float *out, long n)
 {
     if (!x || !comp || !out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
-    int rc = ensure_device();
+    int rc = dss_ensure_device();
     if (rc) return rc;
     float *dx = nullptr, *dc = nullptr, *dout = nullptr;
     rc = dev_upload<float>(x, (size_t)n, &dx) | dev_upload<float>(comp, (size_t)n, &dc) | dev_alloc<float>((size_t)n, &dout);
@@ -1289,7 +1366,7 @@ extern "C" int dss_selftest_exp10(const float *x, const float *comp, float *out,
 extern "C" int dss_selftest_lin2ulaw(unsigned start_bits, unsigned stride, long n, unsigned char *out)
 {
     if (!out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
-    int rc = ensure_device();
+    int rc = dss_ensure_device();
     if (rc) return rc;
     unsigned char *dout = nullptr;
     rc = dev_alloc<unsigned char>((size_t)n, &dout);
@@ -1311,7 +1388,7 @@ extern "C" int dss_hga_num_windows(int T, int sr, float window_length, float win
 extern "C" int dss_hga_log_power(const double *data, int T, int C, int sr, float wl, float ws, double *out)
 {
     if (!data || !out || T <= 0 || C <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
-    int rc = ensure_device();
+    int rc = dss_ensure_device();
     if (rc) return rc;
     const int W = dss_hga_num_windows(T, sr, wl, ws);
     if (W <= 0) return DSS_OK;
@@ -1372,7 +1449,7 @@ extern "C" dss_hga *dss_hga_create(int n_streams, int n_channels, int fs, float 
         dss_set_error("bad HGA arguments (1..8 second-order sections supported)");
         return nullptr;
     }
-    if (ensure_device()) return nullptr;
+    if (dss_ensure_device()) return nullptr;
     dss_hga *h = new dss_hga;
     h->device = g_device;
     DssHgaDev &d = h->d;
@@ -1620,7 +1697,7 @@ extern "C" dss_gate *dss_gate_create(int n_streams, int nb_features, int smoothi
         dss_set_error("bad gate arguments (smoothing window 2*ctx+1 must be <= 64)");
         return nullptr;
     }
-    if (ensure_device()) return nullptr;
+    if (dss_ensure_device()) return nullptr;
     dss_gate *g = new dss_gate;
     g->device = g_device;
     g->max_frames = max_frames;
@@ -1721,6 +1798,28 @@ extern "C" int dss_gate_segment_dev(dss_gate *g, int stream, int event, float *d
     return len;
 }
 
+extern "C" int dss_gate_collect_dev(dss_gate *g, int n, const int *streams, const int *events, const int *dst_rows, float *d_dst,
+                                    int row_frames, void *hip_stream)
+{
+    if (!g || n < 0 || (n && (!streams || !events || !dst_rows || !d_dst))) { dss_set_error("dss_gate_collect_dev: bad arguments"); return DSS_EINVAL; }
+    for (int i = 0; i < n; ++i) {
+        const float *src; int len;
+        int rc = gate_segment_src(g, streams[i], events[i], row_frames, &src, &len);
+        if (rc) return rc;
+        if (dst_rows[i] < 0) { dss_set_error("segment %d: negative destination row", i); return DSS_EINVAL; }
+    }
+    DSS_HIP_CHECK(hipSetDevice(g->device));
+    for (int i0 = 0; i0 < n; i0 += DSS_GATE_COLLECT_MAX) {
+        const int m = std::min(DSS_GATE_COLLECT_MAX, n - i0);
+        DssGateCollect a;
+        memset(&a, 0, sizeof(a));
+        for (int i = 0; i < m; ++i) { a.stream[i] = streams[i0 + i]; a.event[i] = events[i0 + i]; a.dst_row[i] = dst_rows[i0 + i]; }
+        int rc = dss_launch_gate_collect(g->d, a, m, d_dst, (long)row_frames * g->d.C, (hipStream_t)hip_stream);
+        if (rc) return rc;
+    }
+    return n;
+}
+
 extern "C" int dss_gate_segment(dss_gate *g, int stream, int event, float *dst, int cap_frames)
 {
     const float *src; int len;
@@ -1754,7 +1853,11 @@ struct dss_vad {
 extern "C" dss_vad *dss_vad_create(int n_streams, int n_inputs, int hidden_units)
 {
     if (n_streams <= 0 || n_inputs <= 0 || hidden_units <= 0) { dss_set_error("VAD dims must be positive"); return nullptr; }
-    if (ensure_device()) return nullptr;
+    if (hidden_units > DSS_VAD_MAXH || n_inputs > DSS_VAD_MAXC) {
+        dss_set_error("VAD kernel: %d hidden units / %d inputs out of range (<= %d / <= %d)", hidden_units, n_inputs, DSS_VAD_MAXH, DSS_VAD_MAXC);
+        return nullptr;
+    }
+    if (dss_ensure_device()) return nullptr;
     dss_vad *v = new dss_vad;
     memset(&v->d, 0, sizeof(v->d));
     v->device = g_device;
@@ -1801,14 +1904,18 @@ extern "C" int dss_vad_load_weights(dss_vad *v, const float *w_ih0, const float 
         b0[r] = b_ih0[r] + b_hh0[r];
         b1[r] = b_ih1[r] + b_hh1[r];
     }
-    for (float *&p : v->w) { if (p) hipFree(p); p = nullptr; }
-    int rc = dev_upload<float>(t0.data(), t0.size(), &v->w[0]);
-    rc |= dev_upload<float>(b0.data(), b0.size(), &v->w[1]);
-    rc |= dev_upload<float>(t1.data(), t1.size(), &v->w[2]);
-    rc |= dev_upload<float>(b1.data(), b1.size(), &v->w[3]);
-    rc |= dev_upload<float>(cls_w, (size_t)2 * H, &v->w[4]);
-    rc |= dev_upload<float>(cls_b, 2, &v->w[5]);
-    if (rc) return DSS_ENOMEM;
+    // upload beside the weights in use and switch only when every array has arrived: a failed load leaves the detector
+    // as it was (an earlier model keeps running; without one, `loaded` stays false)
+    float *nw[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = dev_upload<float>(t0.data(), t0.size(), &nw[0]);
+    rc |= dev_upload<float>(b0.data(), b0.size(), &nw[1]);
+    rc |= dev_upload<float>(t1.data(), t1.size(), &nw[2]);
+    rc |= dev_upload<float>(b1.data(), b1.size(), &nw[3]);
+    rc |= dev_upload<float>(cls_w, (size_t)2 * H, &nw[4]);
+    rc |= dev_upload<float>(cls_b, 2, &nw[5]);
+    if (rc) { for (float *p : nw) if (p) hipFree(p); return DSS_ENOMEM; }
+    DSS_HIP_CHECK(hipDeviceSynchronize());                    // no launch may still read the arrays about to be freed
+    for (int k = 0; k < 6; ++k) { if (v->w[k]) hipFree(v->w[k]); v->w[k] = nw[k]; }
     v->d.wT0 = v->w[0]; v->d.b0 = v->w[1]; v->d.wT1 = v->w[2]; v->d.b1 = v->w[3]; v->d.wc = v->w[4]; v->d.bc = v->w[5];
     v->loaded = true;
     return DSS_OK;
@@ -1823,6 +1930,21 @@ extern "C" int dss_vad_reset(dss_vad *v, int stream)
     for (float *p : {v->d.h, v->d.c}) {
         if (stream < 0) { DSS_HIP_CHECK(hipMemset(p, 0, 2 * SH * sizeof(float))); continue; }
         for (int layer = 0; layer < 2; ++layer) DSS_HIP_CHECK(hipMemset(p + layer * SH + (size_t)stream * H, 0, H * sizeof(float)));
+    }
+    return DSS_OK;
+}
+
+// the same, enqueued on the stream the steps run on (dss_vad_reset uses the null stream and waits: it is ordered against
+// steps on a blocking stream only)
+extern "C" int dss_vad_reset_async(dss_vad *v, int stream, void *hip_stream)
+{
+    if (!v || stream >= v->d.S) { dss_set_error("bad VAD / stream"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(v->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t SH = (size_t)v->d.S * v->d.H, H = v->d.H;
+    for (float *p : {v->d.h, v->d.c}) {
+        if (stream < 0) { DSS_HIP_CHECK(hipMemsetAsync(p, 0, 2 * SH * sizeof(float), st)); continue; }
+        for (int layer = 0; layer < 2; ++layer) DSS_HIP_CHECK(hipMemsetAsync(p + layer * SH + (size_t)stream * H, 0, H * sizeof(float), st));
     }
     return DSS_OK;
 }
@@ -1858,6 +1980,8 @@ struct dss_dec {
     DssDecDev d;
     float *w[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // wT[2][2], b[2][2], wr, br
     bool loaded = false;
+    int *d_meta = nullptr;        // [2][S_max]: frame counts, input rows of a ragged call (dss_dec_forward_rows_dev)
+    DssPinnedRing meta;           //   their pinned staging
 };
 
 extern "C" dss_dec *dss_dec_create(int max_streams, int max_frames, int n_inputs, int hidden_units, int n_outputs)
@@ -1865,13 +1989,19 @@ extern "C" dss_dec *dss_dec_create(int max_streams, int max_frames, int n_inputs
     if (max_streams <= 0 || max_frames <= 0 || n_inputs <= 0 || hidden_units <= 0 || n_outputs <= 0) {
         dss_set_error("decoder dims must be positive"); return nullptr;
     }
-    if (ensure_device()) return nullptr;
+    if (hidden_units > DSS_DEC_MAXH || n_inputs > DSS_DEC_MAXC || n_outputs > DSS_DEC_MAXO) {
+        dss_set_error("decoder kernel: %d hidden units / %d inputs / %d outputs out of range (<= %d / <= %d / <= %d)", hidden_units, n_inputs,
+                      n_outputs, DSS_DEC_MAXH, DSS_DEC_MAXC, DSS_DEC_MAXO);
+        return nullptr;
+    }
+    if (dss_ensure_device()) return nullptr;
     dss_dec *v = new dss_dec;
     memset(&v->d, 0, sizeof(v->d));
     v->device = g_device;
     v->d.S_max = max_streams; v->d.T_max = max_frames; v->d.C = n_inputs; v->d.H = hidden_units; v->d.O = n_outputs;
     const size_t n = (size_t)max_streams * max_frames * 2 * hidden_units;
-    if (dev_alloc<float>(n, &v->d.mid) || dev_alloc<float>(n, &v->d.top)) {
+    if (dev_alloc<float>(n, &v->d.mid) || dev_alloc<float>(n, &v->d.top) || dev_alloc<int>((size_t)2 * max_streams, &v->d_meta) ||
+        v->meta.init((size_t)2 * max_streams)) {
         dss_set_error("device allocation failed for the decoder's layer outputs");
         dss_dec_destroy(v);
         return nullptr;
@@ -1886,6 +2016,8 @@ extern "C" void dss_dec_destroy(dss_dec *v)
     for (float *p : v->w) if (p) hipFree(p);
     if (v->d.mid) hipFree(v->d.mid);
     if (v->d.top) hipFree(v->d.top);
+    if (v->d_meta) hipFree(v->d_meta);
+    v->meta.destroy();
     delete v;
 }
 
@@ -1898,7 +2030,8 @@ extern "C" int dss_dec_load_weights(dss_dec *v, const float *const *w)
     for (int k = 0; k < 18; ++k) if (!w[k]) { dss_set_error("dss_dec_load_weights: null array %d", k); return DSS_EINVAL; }
     DSS_HIP_CHECK(hipSetDevice(v->device));
     const int H = v->d.H, H4 = 4 * H, Hp = (H + 3) & ~3;
-    for (float *&p : v->w) { if (p) hipFree(p); p = nullptr; }
+    // upload beside the weights in use and switch only when every array has arrived (see dss_vad_load_weights)
+    float *nw[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int rc = 0;
     for (int layer = 0; layer < 2; ++layer) {
         const int Cin = layer ? 2 * H : v->d.C, Cp = (Cin + 3) & ~3;
@@ -1913,15 +2046,17 @@ extern "C" int dss_dec_load_weights(dss_dec *v, const float *const *w)
                 for (int k = 0; k < H; ++k) put(Cp + k, r, w_hh[(size_t)r * H + k]);
                 b[r] = b_ih[r] + b_hh[r];
             }
-            rc |= dev_upload<float>(t.data(), t.size(), &v->w[layer * 2 + dir]);
-            rc |= dev_upload<float>(b.data(), b.size(), &v->w[4 + layer * 2 + dir]);
-            v->d.wT[layer][dir] = v->w[layer * 2 + dir];
-            v->d.b[layer][dir] = v->w[4 + layer * 2 + dir];
+            rc |= dev_upload<float>(t.data(), t.size(), &nw[layer * 2 + dir]);
+            rc |= dev_upload<float>(b.data(), b.size(), &nw[4 + layer * 2 + dir]);
         }
     }
-    rc |= dev_upload<float>(w[16], (size_t)v->d.O * 2 * H, &v->w[8]);
-    rc |= dev_upload<float>(w[17], (size_t)v->d.O, &v->w[9]);
-    if (rc) return DSS_ENOMEM;
+    rc |= dev_upload<float>(w[16], (size_t)v->d.O * 2 * H, &nw[8]);
+    rc |= dev_upload<float>(w[17], (size_t)v->d.O, &nw[9]);
+    if (rc) { for (float *p : nw) if (p) hipFree(p); return DSS_ENOMEM; }
+    DSS_HIP_CHECK(hipDeviceSynchronize());
+    for (int k = 0; k < 10; ++k) { if (v->w[k]) hipFree(v->w[k]); v->w[k] = nw[k]; }
+    for (int layer = 0; layer < 2; ++layer)
+        for (int dir = 0; dir < 2; ++dir) { v->d.wT[layer][dir] = v->w[layer * 2 + dir]; v->d.b[layer][dir] = v->w[4 + layer * 2 + dir]; }
     v->d.wr = v->w[8]; v->d.br = v->w[9];
     v->loaded = true;
     return DSS_OK;
@@ -1936,5 +2071,37 @@ extern "C" int dss_dec_forward_dev(dss_dec *v, const void *d_frames, int frames_
     if (!v || !d_frames || !d_feats) { dss_set_error("dss_dec_forward_dev: bad arguments"); return DSS_EINVAL; }
     if (!v->loaded) { dss_set_error("dss_dec_forward_dev: no weights loaded (dss_dec_load_weights)"); return DSS_EINVAL; }
     DSS_HIP_CHECK(hipSetDevice(v->device));
-    return dss_launch_decoder(v->d, d_frames, frames_are_f64, n_streams, n_frames, d_feats, (hipStream_t)hip_stream);
+    return dss_launch_decoder(v->d, d_frames, frames_are_f64, n_streams, n_frames, d_feats, nullptr, nullptr, 0, (hipStream_t)hip_stream);
+}
+
+// Ragged form (segments of different lengths closing on the same tick): stream i has counts[i] <= n_frames frames, read from
+// row in_rows[i] (NULL: i) of d_frames, a buffer of row_frames frames per row; its backward direction starts at its own last
+// frame.  counts / in_rows are HOST arrays.  d_feats is (n_streams, n_frames, n_outputs); rows beyond counts[i] stay untouched.
+extern "C" int dss_dec_forward_rows_dev(dss_dec *v, const void *d_frames, int frames_are_f64, int row_frames, const int *in_rows,
+                                        const int *counts, int n_streams, int n_frames, float *d_feats, void *hip_stream)
+{
+    if (!v || !d_frames || !d_feats || !counts) { dss_set_error("dss_dec_forward_rows_dev: bad arguments"); return DSS_EINVAL; }
+    if (!v->loaded) { dss_set_error("dss_dec_forward_rows_dev: no weights loaded (dss_dec_load_weights)"); return DSS_EINVAL; }
+    if (n_streams < 1 || n_streams > v->d.S_max || n_frames < 1 || n_frames > v->d.T_max || row_frames < n_frames) {
+        dss_set_error("dss_dec_forward_rows_dev: %d streams x %d frames (rows of %d) exceed the handle's %d x %d", n_streams, n_frames,
+                      row_frames, v->d.S_max, v->d.T_max);
+        return DSS_EINVAL;
+    }
+    for (int i = 0; i < n_streams; ++i) {
+        if (counts[i] < 0 || counts[i] > n_frames) { dss_set_error("stream %d: %d frames outside [0, %d]", i, counts[i], n_frames); return DSS_EINVAL; }
+        if (in_rows && in_rows[i] < 0) { dss_set_error("stream %d: negative input row", i); return DSS_EINVAL; }
+    }
+    DSS_HIP_CHECK(hipSetDevice(v->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    int *h = v->meta.acquire();
+    if (!h) { dss_set_error("pinned staging ring failed"); return DSS_ENODEV; }
+    const size_t S = (size_t)v->d.S_max;
+    memcpy(h, counts, sizeof(int) * n_streams);
+    if (in_rows) memcpy(h + S, in_rows, sizeof(int) * n_streams);
+    DSS_HIP_CHECK(hipMemcpyAsync(v->d_meta, h, sizeof(int) * n_streams, hipMemcpyHostToDevice, s));
+    if (in_rows) DSS_HIP_CHECK(hipMemcpyAsync(v->d_meta + S, h + S, sizeof(int) * n_streams, hipMemcpyHostToDevice, s));
+    int rc = v->meta.commit(s);
+    if (rc) return rc;
+    return dss_launch_decoder(v->d, d_frames, frames_are_f64, n_streams, n_frames, d_feats, v->d_meta, in_rows ? v->d_meta + S : nullptr,
+                              row_frames, s);
 }

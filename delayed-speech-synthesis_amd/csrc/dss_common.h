@@ -166,9 +166,17 @@ struct DssGateDev {
     int *events;                  // [S][2 + max_events]: n_events, n_speech_labels, lengths
 };
 int dss_launch_gate(const DssGateDev &g, const double *d_frames, const int *d_labels, int W, hipStream_t s);
+#define DSS_GATE_COLLECT_MAX 64
+struct DssGateCollect { int stream[DSS_GATE_COLLECT_MAX], event[DSS_GATE_COLLECT_MAX], dst_row[DSS_GATE_COLLECT_MAX]; };
+int dss_launch_gate_collect(const DssGateDev &g, const DssGateCollect &a, int n, float *d_dst, long dst_row_floats, hipStream_t s);
 int dss_launch_gate_reset(const DssGateDev &g, int stream, hipStream_t s);
 
 // ---- neural voice-activity detector (vad_lstm.hip) -----------------------------------------------------------
+#define DSS_VAD_MAXH 160          // capacities of the kernels, checked when a handle is created
+#define DSS_VAD_MAXC 128
+#define DSS_DEC_MAXH 128
+#define DSS_DEC_MAXC 256
+#define DSS_DEC_MAXO 32
 struct DssVadDev {
     int S, C, H;                  // streams, inputs per frame, hidden units (two LSTM layers, two classes)
     const float *wT0;             // [(Cp + Hp) / 4][4H][4]: weight_ih_l0 then weight_hh_l0, four consecutive inputs of a row side by
@@ -190,7 +198,9 @@ struct DssDecDev {
     const float *wr, *br;         // regressor [O][2H], [O]
     float *mid, *top;             // [S_max][T_max][2H] each: the outputs of layer 0 / layer 1 (forward | backward)
 };
-int dss_launch_decoder(const DssDecDev &d, const void *d_frames, int frames_f64, int S, int T, float *d_feats, hipStream_t s);
+// d_counts (frames per stream, <= T), d_in_row (input row of stream s in a buffer of Tin frames per row): device arrays or NULL
+int dss_launch_decoder(const DssDecDev &d, const void *d_frames, int frames_f64, int S, int T, float *d_feats,
+                       const int *d_counts, const int *d_in_row, int Tin, hipStream_t s);
 
 struct DssHgaDev {
     int S, C, fs, nsec;

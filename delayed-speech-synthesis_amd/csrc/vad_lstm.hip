@@ -18,8 +18,8 @@
 #include "dss_common.h"
 
 #define VAD_THREADS 640           // >= 4 * H
-#define VAD_MAXH 160              // (a multiple of 4)
-#define VAD_MAXC 128
+#define VAD_MAXH DSS_VAD_MAXH              // (a multiple of 4)
+#define VAD_MAXC DSS_VAD_MAXC
 #define VAD_TP 4                  // frames whose input halves (W_ih x) are formed in one pass over W_ih
 
 typedef float vf4 __attribute__((ext_vector_type(4)));

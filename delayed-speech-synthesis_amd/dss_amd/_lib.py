@@ -27,6 +27,18 @@ def _declare(L):
         "dss_device_count": (i, []),
         "dss_set_device": (i, [i]),
         "dss_current_device": (i, []),
+        "dss_stream_create": (vp, []),
+        "dss_stream_destroy": (None, [vp]),
+        "dss_stream_synchronize": (i, [vp]),
+        "dss_event_create": (vp, []),
+        "dss_event_destroy": (None, [vp]),
+        "dss_event_record": (i, [vp, vp]),
+        "dss_event_query": (i, [vp]),
+        "dss_event_synchronize": (i, [vp]),
+        "dss_stream_wait_event": (i, [vp, vp]),
+        "dss_host_alloc": (vp, [sz, i]),
+        "dss_host_free": (None, [vp]),
+        "dss_memcpy_d2h_async": (i, [vp, vp, sz, vp]),
         "lpcnet_create": (vp, []),
         "lpcnet_init": (i, [vp]),
         "lpcnet_destroy": (None, [vp]),
@@ -48,6 +60,7 @@ def _declare(L):
         "dss_lpcnet_bytes_per_sample": (C.c_double, []),
         "dss_lpcnet_batch_create": (vp, [i, i]),
         "dss_lpcnet_batch_destroy": (None, [vp]),
+        "dss_lpcnet_batch_create_lane": (vp, [vp, i, i]),
         "dss_lpcnet_batch_reset": (i, [vp, i]),
         "dss_lpcnet_batch_reset_async": (i, [vp, i, vp]),
         "dss_lpcnet_batch_synthesize": (i, [vp, vp, i, i, i, vp]),
@@ -67,17 +80,20 @@ def _declare(L):
         "dss_gate_push_dev": (i, [vp, vp, vp, i, vp, vp]),
         "dss_gate_segment": (i, [vp, i, i, vp, i]),
         "dss_gate_segment_dev": (i, [vp, i, i, vp, i, vp]),
+        "dss_gate_collect_dev": (i, [vp, i, vp, vp, vp, vp, i, vp]),
         "dss_gate_frames_seen": (i, [vp, i]),
         "dss_vad_create": (vp, [i, i, i]),
         "dss_vad_destroy": (None, [vp]),
         "dss_vad_load_weights": (i, [vp] * 11),
         "dss_vad_reset": (i, [vp, i]),
+        "dss_vad_reset_async": (i, [vp, i, vp]),
         "dss_vad_step_dev": (i, [vp, vp, i, i, vp, vp, vp]),
         "dss_vad_state": (i, [vp, vp, vp, i]),
         "dss_dec_create": (vp, [i, i, i, i, i]),
         "dss_dec_destroy": (None, [vp]),
         "dss_dec_load_weights": (i, [vp, vp]),
         "dss_dec_forward_dev": (i, [vp, vp, i, i, i, vp, vp]),
+        "dss_dec_forward_rows_dev": (i, [vp, vp, i, i, vp, vp, i, i, vp, vp]),
         "dss_hga_num_windows": (i, [i, i, f, f]),
         "dss_hga_log_power": (i, [vp, i, i, i, f, f, vp]),
         "dss_hga_create": (vp, [i, i, i, f, f, i, vp, vp, vp, vp]),

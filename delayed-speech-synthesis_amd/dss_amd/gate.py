@@ -75,6 +75,20 @@ class SpeechGateGPU:
         _lib.check(self._L.dss_gate_push_dev(self._h, frames.data_ptr(), labels.data_ptr(), W, self._events.ctypes.data, s))
         return self._events
 
+    def collect_torch(self, streams, events, dst_rows, pool, hip_stream=None):
+        """Segments (streams[i], events[i]) of the last push -> rows dst_rows[i] of ``pool`` (CUDA float32 (rows, row_frames, C)) in
+        one launch (``dss_gate_collect_dev``), asynchronous on the current stream."""
+        import torch
+        assert pool.is_cuda and pool.dtype == torch.float32 and pool.is_contiguous() and pool.dim() == 3 and pool.shape[2] == self.C
+        st = np.ascontiguousarray(streams, dtype=np.int32)
+        ev = np.ascontiguousarray(events, dtype=np.int32)
+        dr = np.ascontiguousarray(dst_rows, dtype=np.int32)
+        if not (st.shape == ev.shape == dr.shape) or (dr.size and int(dr.max()) >= pool.shape[0]):
+            raise ValueError("streams / events / dst_rows must have one entry per segment, rows inside the pool")
+        s = torch.cuda.current_stream().cuda_stream if hip_stream is None else hip_stream
+        _lib.check(self._L.dss_gate_collect_dev(self._h, int(st.size), st.ctypes.data, ev.ctypes.data, dr.ctypes.data, pool.data_ptr(),
+                                                int(pool.shape[1]), s))
+
     def segment_torch(self, stream: int, event: int = 0):
         """Segment `event` completed by `stream` in the last push, as a CUDA float32 tensor (L, C)."""
         import torch

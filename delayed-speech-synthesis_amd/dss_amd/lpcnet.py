@@ -101,6 +101,21 @@ class LPCNetBatch:
                           "h blocks %d of 64, LDS image %d of 151552 B): running on the generic kernel, several times slower"
                           % (info["zr_slots_max"], info["h_slots_max"], info["h_lds_bytes"]), RuntimeWarning, stacklevel=2)
 
+    def create_lane(self, max_rows: int, max_frames: int) -> "LPCNetBatch":
+        """A second launch context on THIS batch's decoder slots (``dss_lpcnet_batch_create_lane``): it owns per-call scratch
+        for max_rows x max_frames, its ragged calls name this batch's slots.  Calls on different lanes may be in flight on
+        different streams at once as long as no slot is in two of them (the caller orders a slot's calls)."""
+        L = self._L
+        _lib.check(L.dss_set_device(self.device))
+        h = L.dss_lpcnet_batch_create_lane(self._h, int(max_rows), int(max_frames))
+        if not h:
+            raise _lib.DssError(L.dss_last_error().decode())
+        lane = object.__new__(LPCNetBatch)
+        lane._L, lane._h, lane.device = L, h, self.device
+        lane.max_utts, lane.max_frames = int(max_rows), int(max_frames)
+        lane._parent = self                      # keeps the slots alive as long as the lane
+        return lane
+
     def _check_device(self, t):
         """Kernels of this batch run on self.device; a tensor from another GPU would be a silent peer access."""
         if t.device.index != self.device:

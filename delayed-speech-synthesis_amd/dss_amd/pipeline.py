@@ -40,7 +40,7 @@ class _DecoderMixin:
         library's own kernels (dss_dec_forward_dev: all streams, all frames of the call, zero initial state); any other module
         is called as given, on PyTorch-ROCm."""
         from . import decoder as _dec
-        self.dec_gpu = _dec.BiLstmDecoderGPU(max_streams, max_frames, self.decoder) if (use_kernel and _dec.fits(self.decoder)) else None
+        self.dec_gpu = _dec.make_kernel(self.decoder, max_streams, max_frames) if use_kernel else None       # fits() + a probe of forward()
 
     def _decode(self, x):
         """x: CUDA (B, T, C) float64 or float32 -> float32 (B, T, 20), from a fresh zero state (units.py:499-508)."""
@@ -173,17 +173,23 @@ class StreamingPipeline(_DecoderMixin):
 
 class GatedStreamingPipeline(_DecoderMixin):
     """S streams through HighGammaActivity -> FilterSpeechSegments -> RecurrentNeuralDecodingModel ->
-    DelayedLPCNetVocoder (decode_online.py:115-135), all streams per tick in batched launches."""
+    DelayedLPCNetVocoder (decode_online.py:115-135), all streams per tick in batched launches.
+
+    The tick (extractor, detector, gate: three launches for all streams) never waits for a vocoder.  Segments that close
+    on a tick are handed to a ``SegmentSynthesisQueue`` (side streams: whole-segment decoder + ragged vocoder launch + PCM
+    copy per job) and ``push()`` returns the segments FINISHED since the last tick.  The reference's own behaviour -- its
+    one stream blocks while it vocodes (units.py:531-538) -- is ``asynchronous=False``: every tick then waits for what it
+    started, and returns it."""
 
     def __init__(self, n_streams: int, n_channels: int = 64, fs: int = 1000, packet: int = 40,
                  buffer_size: int = 2000, context_frames: int = 50, smoothing_context: int = 5,
                  channel_means: Optional[np.ndarray] = None, channel_stds: Optional[np.ndarray] = None,
                  decoder: Optional[torch.nn.Module] = None, vad: Optional[torch.nn.Module] = None, seed: int = 0,
-                 max_segment_frames: Optional[int] = None, use_vad_kernel: bool = True, use_decoder_kernel: bool = True):
+                 max_segment_frames: Optional[int] = None, use_vad_kernel: bool = True, use_decoder_kernel: bool = True,
+                 asynchronous: bool = True, n_lanes: int = 3, rows_per_job: int = 32):
         self.S, self.C, self.packet = n_streams, n_channels, packet
         self.hga = HgaExtractorGPU(n_streams, n_channels, fs=fs)
         self.decoder = self._make_decoder(n_channels, decoder, seed)
-        self._make_decoder_kernel(1, int(max_segment_frames or buffer_size), use_decoder_kernel)
         if vad is None:
             from .models import UnidirectionalVoiceActivityDetector
             torch.manual_seed(seed + 1)     # no trained checkpoint exists offline: seeded random weights
@@ -193,12 +199,22 @@ class GatedStreamingPipeline(_DecoderMixin):
         # kernel (dss_vad_step_dev: all streams, all frames of the packet, state carried in HBM); any other module is called as
         # given, on PyTorch-ROCm.
         from . import vad as _vad
-        self.vad_gpu = _vad.VadLstmGPU(n_streams, self.vad) if (use_vad_kernel and _vad.fits(self.vad)) else None
+        self.vad_gpu = _vad.make_kernel(self.vad, n_streams) if use_vad_kernel else None                    # fits() + a probe of forward()
         self.vad_state = None if self.vad_gpu else self.vad.create_new_initial_state(batch_size=n_streams, device="cuda")
         max_w = packet // max(1, int(0.01 * fs)) + 1      # frames one packet can complete (10 ms shift)
         self.gate = SpeechGateGPU(n_streams, n_channels, buffer_size, context_frames, smoothing_context, 0.6, max_frames=max_w)
         self.seg_cap = int(max_segment_frames or buffer_size)
-        self.vocoder = LPCNetBatch(n_streams, self.seg_cap)       # slot = stream: vocoder state carries across segments
+        self.vocoder = LPCNetBatch(n_streams, 1)                  # slot = stream: vocoder state carries across segments;
+        #                                                           every launch runs on a lane of it (own scratch)
+        from . import decoder as _dec
+        from .segment_queue import SegmentSynthesisQueue
+        self._make_decoder_kernel(1, self.seg_cap, use_decoder_kernel)     # (one whole segment: the probe of forward(), and _decode())
+        kernel_ok = self.dec_gpu is not None
+        factory = (lambda rows, frames: _dec.BiLstmDecoderGPU(rows, frames, self.decoder)) if kernel_ok else None
+        self.asynchronous = bool(asynchronous)
+        self.queue = SegmentSynthesisQueue(self.gate, self.vocoder, n_channels, self.seg_cap, decoder_factory=factory,
+                                           decoder_module=self.decoder, n_lanes=n_lanes if asynchronous else 1,
+                                           rows_per_job=min(rows_per_job, n_streams) if asynchronous else n_streams)
         mean = np.zeros(n_channels) if channel_means is None else np.asarray(channel_means, dtype=np.float64)
         std = np.ones(n_channels) if channel_stds is None else np.asarray(channel_stds, dtype=np.float64)
         self.mean, self.std = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
@@ -209,16 +225,18 @@ class GatedStreamingPipeline(_DecoderMixin):
         self.frame_counter = 0
         self.last_labels = None           # raw VAD decisions and z-scored frames of the last tick (test taps)
         self.last_z = None
+        self.segments_closed = 0
 
     @torch.no_grad()
     def push(self, packets: np.ndarray):
-        """packets: host float64 (S, packet, C).  Returns a list of (stream, previous_frames, pcm int16 host array)
-        for every speech segment that closed on this tick (usually empty)."""
+        """packets: host float64 (S, packet, C).  Returns a list of (stream, previous_frames, pcm int16 host array): the
+        speech segments whose audio has FINISHED since the last call (asynchronous mode; a stream's segments always in
+        closing order), or the segments that closed on this tick (asynchronous=False: the tick waits for them)."""
         self._in.copy_(torch.from_numpy(np.ascontiguousarray(packets, dtype=np.float64)))
         hga = self.hga.extract_torch(self._in, apply_log=True)                       # (S, W, C) float64
         W = hga.shape[1]
         if W == 0:
-            return []
+            return self.queue.poll()
         # post-transform (ZScoreNormalization): already applied inside the launch when the channel count allows
         z = hga if self._zs_in_kernel else ((hga - self.mean) / self.std).contiguous()
         if self.vad_gpu is not None:                                                 # units.py:433-434 in one launch
@@ -229,23 +247,23 @@ class GatedStreamingPipeline(_DecoderMixin):
         self.last_labels, self.last_z = labels, z
         events = self.gate.push_torch(z, labels)
         self.frame_counter += W
-        out = []
-        for e in range(self.gate.E):                     # a stream closes at most one segment per tick in practice
-            streams = [s for s in range(self.S) if events[s, 0] > e]
-            if not streams:
-                break
-            counts = [int(events[s, 2 + e]) for s in streams]
-            fmax = max(counts)
-            if fmax > self.seg_cap:
-                raise ValueError(f"segment of {fmax} frames exceeds max_segment_frames={self.seg_cap}")
-            feats = torch.zeros((len(streams), max(fmax, 1), 20), dtype=torch.float32, device="cuda")
-            for k, s in enumerate(streams):              # whole-segment bidirectional decode, fresh state (units.py:499-508)
-                if counts[k] == 0:
-                    continue
-                seg = self.gate.segment_torch(s, e)
-                feats[k, :counts[k]] = self._decode(seg[None])[0]
-            pcm = self.vocoder.synthesize_ragged_torch(feats, counts, slots=streams).cpu().numpy()
-            for k, s in enumerate(streams):
-                previous = self.frame_counter - counts[k] - (W - int(events[s, 1]))    # units.py:445
-                out.append((s, previous, pcm[k, :counts[k] * FRAME_SIZE].copy()))
-        return out
+        closers = np.flatnonzero(events[:, 0])
+        if closers.size:
+            streams, evs, lengths, tags = [], [], [], []
+            for e in range(self.gate.E):                 # a stream closes at most one segment per tick in practice
+                for s in closers:
+                    if events[s, 0] > e:
+                        n = int(events[s, 2 + e])
+                        streams.append(int(s)); evs.append(e); lengths.append(n)
+                        tags.append(self.frame_counter - n - (W - int(events[s, 1])))       # previous_frames, units.py:445
+            self.segments_closed += len(streams)
+            self.queue.submit(streams, evs, lengths, tags)
+        return self.queue.drain() if not self.asynchronous else self.queue.poll()
+
+    def poll(self):
+        """Segments finished since the last push()/poll() (a host between ticks may call this as often as it likes)."""
+        return self.queue.poll()
+
+    def flush(self):
+        """Wait for every segment that has closed so far; returns their (stream, previous_frames, pcm)."""
+        return self.queue.drain()

@@ -10,8 +10,10 @@ What it does before handing control to the script (runpy, ``__main__``):
      run directly) and replaces in them exactly the classes whose work moves to the GPU:
         local.units.HighGammaExtractor      -> dss_amd.units.HighGammaExtractor      (fused IIR + framing + log power)
         local.units.DelayedLPCNetVocoder    -> dss_amd.units.DelayedLPCNetVocoder    (whole segment per launch)
-        local.units.RecurrentNeuralDecodingModel -> dss_amd.units.RecurrentNeuralDecodingModel (the reference's decoder
-                                               architecture on the library's kernels; other modules as they are)
+        local.units.RecurrentNeuralDecodingModel -> dss_amd.units.gpu_decoding_unit(<the user's class>): a SUBCLASS of the
+                                               user's own unit -- its initialize() is the user's, its decode() runs the
+                                               reference's decoder architecture on the library's kernels (other modules
+                                               go through the user's own handler)
         local.training.AsynchronousSynthesisQueue -> dss_amd.synthesis_queue.AsynchronousSynthesisQueue
      ``HighGammaActivity.initialize`` (units.py:199-201) looks HighGammaExtractor up in its module at run time, so the
      reference's own unit class picks the GPU extractor up; every other unit is the user's code, untouched.
@@ -47,7 +49,10 @@ def install(verbose: bool = True) -> dict:
         if not hasattr(mod, attr):
             report[key] = f"left alone: {mod_name} has no {attr}"
             continue
-        setattr(mod, attr, getattr(importlib.import_module(ours), attr))
+        if attr == "RecurrentNeuralDecodingModel":       # wrapped, not replaced: a subclass of the user's own class
+            setattr(mod, attr, importlib.import_module(ours).gpu_decoding_unit(getattr(mod, attr)))
+        else:
+            setattr(mod, attr, getattr(importlib.import_module(ours), attr))
         report[key] = "replaced"
     if verbose:
         for k, v in report.items():

@@ -6,8 +6,9 @@ reference's local/units.py classes of the same names (settings, stream names, me
   HighGammaActivity    (units.py:185-207)  unit wrapper, msg.fs = 1 / window_shift
   DelayedLPCNetVocoder (units.py:517-538)  a whole decoded segment per launch of the persistent sample-rate kernel;
                                            one decoder state for the unit's lifetime, as units.py:524
-  RecurrentNeuralDecodingModel (units.py:450-508)  the reference's own decoder architecture on the library's kernels
-                                           (three launches per segment), any other module as PyTorch-ROCm
+  gpu_decoding_unit(user's RecurrentNeuralDecodingModel) (units.py:472-508)  a SUBCLASS of the user's own unit: its
+                                           initialize() stays the user's, decode() runs the reference's decoder architecture
+                                           on the library's kernels (three launches per segment), any other module as it was
 
 Everything else of the reference's unit module (ZMQ source, loggers, VAD gate, SoX sink) is I/O or stock
 PyTorch and stays the user's own code: ``python -m dss_amd.run decode_online.py ...`` swaps exactly the classes above
@@ -146,62 +147,56 @@ class HighGammaActivity(ez.Unit):
         yield self.OUTPUT, replace(msg, data=frames, fs=1 / self.SETTINGS.window_shift)
 
 
-class RecurrentNeuralDecodingModelSettings(ez.Settings):
-    """As the reference's (units.py:450-459): where the state_dict lives, the module class that builds the architecture, and the
-    keyword arguments of its constructor."""
-    path_to_model_weights: Optional[str]
-    model: Callable
-    params: Optional[dict]
-    config_filename: Optional[str] = None
+def gpu_decoding_unit(base):
+    """The user's own ``RecurrentNeuralDecodingModel`` (units.py:472-508) with its forward pass on the library's kernels.
+
+    ``python -m dss_amd.run`` calls this with the class it finds in the user's ``local.units``: the subclass keeps the
+    settings, state, streams and -- by calling it -- the ``initialize()`` of the user's class (building the module, loading the
+    state_dict, ``eval()``, the initial state all stay the user's code), then looks at the module that came out: the
+    reference's architecture (2-layer bidirectional LSTM + linear head, models.py:36-58, checked by parameter shapes AND a
+    probe of its ``forward``) gets ``decode`` in three launches of csrc/bilstm_decoder.hip from the same weights; any other
+    module -- or no GPU -- is called exactly as the base class calls it."""
+    import inspect
+
+    class RecurrentNeuralDecodingModel(base):
+        __doc__ = gpu_decoding_unit.__doc__
+        MAX_SEGMENT_FRAMES = 2200            # FilterSpeechSegments' ring holds 2000 frames (decode_online.py:116)
+
+        def initialize(self) -> None:
+            r = super().initialize()
+            st = self.STATE
+            st.kernel = None
+            if str(getattr(st, "device", "cpu")).startswith("cuda") and getattr(st, "decoding_model", None) is not None:
+                from . import decoder as _dec
+                st.kernel = _dec.make_kernel(st.decoding_model, 1, self.MAX_SEGMENT_FRAMES)
+            return r
+
+        @ez.subscriber(getattr(base, "INPUT", None))
+        @ez.publisher(getattr(base, "OUTPUT", None))
+        async def decode(self, msg: TimeSeriesMessage) -> AsyncGenerator:
+            k = getattr(self.STATE, "kernel", None)
+            n = int(np.shape(msg.data)[0])
+            if k is None or not (1 <= n <= k.T):
+                async for item in super().decode(msg):          # the user's own handler, as it is
+                    yield item
+                return
+            import torch
+            x = torch.from_numpy(np.expand_dims(msg.data, 0)).float().cuda()
+            yield self.OUTPUT, replace(msg, data=k(x)[0].cpu().numpy(), fs=100)
+
+    RecurrentNeuralDecodingModel.__module__ = __name__
+    RecurrentNeuralDecodingModel.__qualname__ = "RecurrentNeuralDecodingModel"
+    if not inspect.isclass(base):
+        raise TypeError("gpu_decoding_unit needs the user's unit CLASS")
+    return RecurrentNeuralDecodingModel
 
 
-class RecurrentNeuralDecodingModelState(ez.State):
-    decoding_model = None
-    device: Optional[str] = None
-    H = None
-    kernel = None                        # dss_amd.decoder.BiLstmDecoderGPU when the model is the reference's architecture
+from ._standin_units import (RecurrentNeuralDecodingModelSettings, RecurrentNeuralDecodingModelState,   # noqa: E402
+                             StandInDecodingUnit)
 
-
-class RecurrentNeuralDecodingModel(ez.Unit):
-    """A whole speech segment of high-gamma frames (L, C) -> LPCNet features (L, 20) at 100 Hz (units.py:472-508): the model
-    is built and loaded exactly as the reference does; when it is the reference's own architecture (2-layer bidirectional
-    LSTM + linear head, models.py:36-58) its forward pass runs in three launches of the library's kernels
-    (csrc/bilstm_decoder.hip) from the same state_dict, otherwise -- or without a GPU -- as the PyTorch module.  Every
-    segment starts from a fresh zero state (units.py:506-507)."""
-    SETTINGS: RecurrentNeuralDecodingModelSettings
-    STATE: RecurrentNeuralDecodingModelState
-    INPUT = ez.InputStream(TimeSeriesMessage)
-    OUTPUT = ez.OutputStream(TimeSeriesMessage)
-    MAX_SEGMENT_FRAMES = 2200            # FilterSpeechSegments' ring holds 2000 frames (decode_online.py:116)
-
-    def initialize(self) -> None:
-        import torch
-        params = self.SETTINGS.params if self.SETTINGS.params is not None else dict()
-        self.STATE.device = "cuda" if torch.cuda.is_available() else "cpu"
-        self.STATE.decoding_model = self.SETTINGS.model(**params).to(self.STATE.device)
-        if self.SETTINGS.path_to_model_weights is not None:
-            self.STATE.decoding_model.load_state_dict(torch.load(self.SETTINGS.path_to_model_weights, map_location=self.STATE.device))
-        self.STATE.decoding_model.eval()
-        self.STATE.H = self.STATE.decoding_model.create_new_initial_state(batch_size=1, device=self.STATE.device)
-        self.STATE.kernel = None
-        if self.STATE.device == "cuda":
-            from . import decoder as _dec
-            if _dec.fits(self.STATE.decoding_model):
-                self.STATE.kernel = _dec.BiLstmDecoderGPU(1, self.MAX_SEGMENT_FRAMES, self.STATE.decoding_model)
-
-    @ez.subscriber(INPUT)
-    @ez.publisher(OUTPUT)
-    async def decode(self, msg: TimeSeriesMessage) -> AsyncGenerator:
-        import torch
-        x = torch.from_numpy(np.expand_dims(msg.data, 0)).float().to(self.STATE.device)
-        k = self.STATE.kernel
-        if k is not None and 1 <= x.shape[1] <= k.T:
-            predictions = k(x)
-        else:
-            with torch.no_grad():
-                predictions, _ = self.STATE.decoding_model(x, self.STATE.H)
-            self.STATE.H = self.STATE.decoding_model.create_new_initial_state(batch_size=1, device=self.STATE.device)
-        yield self.OUTPUT, replace(msg, data=np.squeeze(predictions.detach().cpu().numpy(), axis=0), fs=100)
+# Without the user's tree (tests, this image: no ezmsg / zmq / mne, so the reference's local/units.py cannot be imported) the
+# factory is applied to a stand-in of the user's class; `python -m dss_amd.run` never uses this name, it wraps the real one.
+RecurrentNeuralDecodingModel = gpu_decoding_unit(StandInDecodingUnit)
 
 
 class LPCNetState(ez.State):

@@ -24,10 +24,39 @@ def fits(module) -> bool:
         return False
     if set(sd.keys()) != set(_KEYS):
         return False
+    if any(str(getattr(v, "dtype", "")) not in ("torch.float32", "float32") for v in sd.values()):
+        return False                                   # float64 / half weights: the module's own arithmetic, not this kernel's
     h4, c = sd["lstm.weight_ih_l0"].shape
     h = h4 // 4
     return (h4 == 4 * h and h <= 160 and c <= 128 and tuple(sd["lstm.weight_hh_l0"].shape) == (h4, h)
             and tuple(sd["lstm.weight_ih_l1"].shape) == (h4, h) and tuple(sd["classifier.weight"].shape) == (2, h))
+
+
+def make_kernel(module, n_streams: int, tol: float = 1e-4):
+    """The kernel form of `module`, or None when the module has to run as it is: ``fits`` reads parameter names and shapes, this
+    also checks what the module's ``forward`` does -- its logits on 8 random frames from the zero state must be the kernel's
+    within `tol` (see dss_amd.decoder.make_kernel)."""
+    if not fits(module):
+        return None
+    import torch
+    import warnings
+    k = VadLstmGPU(n_streams, module)
+    try:
+        dev = next(module.parameters()).device
+        x = np.random.default_rng(20240301).standard_normal((1, 8, k.C)).astype(np.float32)
+        with torch.no_grad():
+            want, _ = module(torch.from_numpy(x).to(dev), module.create_new_initial_state(batch_size=1, device=str(dev)))
+        probe = VadLstmGPU(1, module)
+        _, got = probe.step_torch(torch.from_numpy(x).cuda(), want_logits=True)
+        err = float((got - want.to(got.device)).abs().max())
+    except Exception as e:
+        warnings.warn(f"detector probe failed ({type(e).__name__}: {e}); running the module as given", RuntimeWarning, stacklevel=2)
+        return None
+    if not err <= tol:
+        warnings.warn(f"detector module has the reference's parameters but its forward differs from LSTM + Linear by {err:.3g} on a "
+                      "probe; running the module as given (PyTorch-ROCm), not the kernel", RuntimeWarning, stacklevel=2)
+        return None
+    return k
 
 
 class VadLstmGPU:
@@ -47,8 +76,12 @@ class VadLstmGPU:
             self._L.dss_vad_destroy(self._h)
             self._h = None
 
-    def reset(self, stream: int = -1):
-        _lib.check(self._L.dss_vad_reset(self._h, int(stream)))
+    def reset(self, stream: int = -1, hip_stream=None):
+        """Zero state of one stream (or all).  Enqueued on the stream the steps run on (torch's current one by default), so it is
+        ordered against steps in flight whatever kind of stream that is."""
+        import torch
+        s = torch.cuda.current_stream().cuda_stream if hip_stream is None else hip_stream
+        _lib.check(self._L.dss_vad_reset_async(self._h, int(stream), s))
 
     def step_torch(self, frames, want_logits: bool = False):
         """frames: CUDA (S, W, C) float64 or float32.  Returns int32 CUDA labels (S, W) [, float32 logits (S, W, 2)]."""

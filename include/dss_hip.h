@@ -50,6 +50,28 @@ int dss_set_device(int device);
 int dss_current_device(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * Part 0 -- streams, events and page-locked host memory as plain handles, for hosts that keep several calls of this
+ * library in flight at once (the asynchronous segment synthesis of the gated streaming mode) without binding a HIP
+ * runtime themselves.  A stream handle is what every *_dev entry point takes as `hip_stream` (a hipStream_t); streams
+ * created here do not synchronise with the null stream.  Nothing in the reference corresponds to these: its one stream
+ * blocks while it vocodes (local/units.py:531-538).
+ * ---------------------------------------------------------------------------------------------- */
+void *dss_stream_create(void);
+void dss_stream_destroy(void *hip_stream);
+int dss_stream_synchronize(void *hip_stream);
+void *dss_event_create(void);
+void dss_event_destroy(void *event);
+int dss_event_record(void *event, void *hip_stream);
+int dss_event_query(void *event);                 /* 1 = finished, 0 = not yet, < 0 = error */
+int dss_event_synchronize(void *event);
+int dss_stream_wait_event(void *hip_stream, void *event);
+/* Page-locked host memory (results that arrive by asynchronous copy).  cached != 0: ordinary cacheable pages, valid to
+ * read once the copy's event has completed; 0: coherent pages. */
+void *dss_host_alloc(size_t bytes, int cached);
+void dss_host_free(void *p);
+int dss_memcpy_d2h_async(void *host_dst, const void *d_src, size_t bytes, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Part 1 -- xiph LPCNet decoder symbols, as bound by extensions/lpcnet/cLPCNet.pxd:10-13
  * ---------------------------------------------------------------------------------------------- */
 typedef struct LPCNetState LPCNetState;
@@ -111,6 +133,14 @@ typedef struct dss_lpcnet_batch dss_lpcnet_batch;
 
 dss_lpcnet_batch *dss_lpcnet_batch_create(int max_utts, int max_frames);
 void dss_lpcnet_batch_destroy(dss_lpcnet_batch *b);
+/* A lane: a second launch context on the decoder slots of `parent` (which must not itself be a lane).  It owns the per-call
+ * scratch for max_rows x max_frames and nothing else; its calls are ragged calls whose slot list names the parent's slots.
+ * Calls on DIFFERENT lanes (and on the parent) may be in flight on different streams at the same time as long as no slot
+ * is in two of them at once -- the caller orders a slot's calls (an event between them).  That is the many-stream form
+ * of the reference's one vocoder whose state carries from segment to segment (local/units.py:524,531-538): segments that
+ * close on different streams are synthesised side by side, a stream's own segments one after the other.  Destroy with
+ * dss_lpcnet_batch_destroy; a parent destroyed first is released with its last lane. */
+dss_lpcnet_batch *dss_lpcnet_batch_create_lane(dss_lpcnet_batch *parent, int max_rows, int max_frames);
 /* lpcnet_init() on every slot (or on slot `utt` only when utt >= 0). */
 int dss_lpcnet_batch_reset(dss_lpcnet_batch *b, int utt);
 /* Same, enqueued on `hip_stream` without waiting (for device-resident pipelines and timed loops). */
@@ -259,6 +289,11 @@ int dss_gate_push_dev(dss_gate *g, const double *d_frames, const int *d_labels, 
  * cap_frames rows.  Returns its length. */
 int dss_gate_segment(dss_gate *g, int stream, int event, float *dst, int cap_frames);
 int dss_gate_segment_dev(dss_gate *g, int stream, int event, float *d_dst, int cap_frames, void *hip_stream);
+/* The same for n segments of the LAST push in one launch: segment (streams[i], events[i]) goes to row dst_rows[i] of d_dst, a
+ * device buffer of row_frames frames per row ((rows, row_frames, nb_features) float32: a pool of segment buffers that outlive
+ * the next push).  streams / events / dst_rows are HOST arrays.  Returns n. */
+int dss_gate_collect_dev(dss_gate *g, int n, const int *streams, const int *events, const int *dst_rows, float *d_dst,
+                         int row_frames, void *hip_stream);
 /* Frames this stream has been pushed since the last reset (FilterSpeechSegments' frame_counter). */
 int dss_gate_frames_seen(dss_gate *g, int stream);
 
@@ -279,8 +314,11 @@ void dss_vad_destroy(dss_vad *v);
 int dss_vad_load_weights(dss_vad *v, const float *w_ih0, const float *w_hh0, const float *b_ih0, const float *b_hh0,
                          const float *w_ih1, const float *w_hh1, const float *b_ih1, const float *b_hh1,
                          const float *cls_w, const float *cls_b);
-/* Zero state (create_new_initial_state, models.py:22-24) of one stream, or of all (stream < 0). */
+/* Zero state (create_new_initial_state, models.py:22-24) of one stream, or of all (stream < 0).  dss_vad_reset runs on the
+ * null stream and waits: it is ordered against steps issued on a blocking stream only.  dss_vad_reset_async is enqueued on
+ * `hip_stream` -- pass the stream the steps run on. */
 int dss_vad_reset(dss_vad *v, int stream);
+int dss_vad_reset_async(dss_vad *v, int stream, void *hip_stream);
 /* All streams advance by n_frames.  Device pointers, enqueued on hip_stream: d_frames (n_streams, n_frames, n_inputs)
  * float64 (frames_are_f64 != 0: as dss_hga_extract_dev returns them; cast to float32 like units.py:433) or float32;
  * d_labels (n_streams, n_frames) int32, 1 = speech -- what dss_gate_push_dev takes; d_logits (n_streams, n_frames, 2)
@@ -313,6 +351,12 @@ int dss_dec_load_weights(dss_dec *v, const float *const *w);
  * dss_lpcnet_batch_synthesize_dev takes. */
 int dss_dec_forward_dev(dss_dec *v, const void *d_frames, int frames_are_f64, int n_streams, int n_frames, float *d_feats,
                         void *hip_stream);
+/* Ragged form -- the segments that closed on one tick, each decoded as a whole from a fresh state (units.py:499-508), in one
+ * call: stream i has counts[i] <= n_frames frames, read from row in_rows[i] (NULL: i) of d_frames, a buffer of row_frames >=
+ * n_frames frames per row (what dss_gate_collect_dev fills); its backward direction starts at its OWN last frame.  counts /
+ * in_rows are HOST arrays.  d_feats is (n_streams, n_frames, n_outputs); rows beyond counts[i] are left untouched. */
+int dss_dec_forward_rows_dev(dss_dec *v, const void *d_frames, int frames_are_f64, int row_frames, const int *in_rows,
+                             const int *counts, int n_streams, int n_frames, float *d_feats, void *hip_stream);
 
 #ifdef __cplusplus
 }

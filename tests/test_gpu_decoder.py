@@ -139,3 +139,60 @@ def test_decoder_unit_runs_the_kernels_for_the_reference_architecture(golden, tm
     assert other.STATE.kernel is None
     (_, msg), = asyncio.run(drive(other.decode(U.ClosedLoopMessage(data=x[:9].astype(np.float64), fs=100))))
     assert msg.data.shape == (9, 20)
+
+
+@pytest.mark.parametrize("S,T", [(129, 4), (257, 5), (1024, 4), (1023, 5)])
+def test_decoder_kernel_several_streams_per_workgroup(S, T):
+    """Beyond 128 streams a workgroup carries two streams (129 .. 256) or four (the W = 2 / W = 4 instantiations, [unit][stream]
+    LDS layout, cell ownership by (stream, unit)); odd stream counts leave the last workgroup partly empty.  Against
+    torch.nn.LSTM on the same weights, 2e-5."""
+    from dss_amd.decoder import BiLstmDecoderGPU
+    m = _model().cuda()
+    k = BiLstmDecoderGPU(S, T, m)
+    z = torch.from_numpy(np.random.default_rng(S + T).standard_normal((S, T, 64)) * 2.0).cuda()
+    with torch.no_grad():
+        want, _ = m(z.to(torch.float32), m.create_new_initial_state(batch_size=S, device="cuda"))
+    got = k(z)
+    assert got.shape == want.shape and (got - want).abs().max().item() <= 2e-5
+    assert torch.equal(k(z), got)
+    f32 = k(z.to(torch.float32))
+    assert torch.equal(f32, got)
+
+
+@pytest.mark.parametrize("n", [5, 150, 300])
+def test_decoder_ragged_rows_equal_one_call_per_segment(n):
+    """dss_dec_forward_rows_dev: n segments of different lengths (one of them empty), read from scattered rows of a pool whose
+    rows are longer than the call, in one call -- each segment's features are bit-identical to the plain call on that segment
+    alone (same kernels, same order of operations; the backward direction starts at the segment's own last frame), nothing is
+    written beyond a segment's length.  n = 150 / 300 run two / four segments per workgroup with unequal lengths."""
+    from dss_amd.decoder import BiLstmDecoderGPU
+    m = _model().cuda()
+    rng = np.random.default_rng(n)
+    cap, fmax = 40, 33
+    counts = rng.integers(1, fmax + 1, n)
+    counts[1] = 0
+    counts[2] = fmax
+    rows = rng.permutation(n + 7)[:n]
+    pool = torch.from_numpy(rng.standard_normal((n + 7, cap, 64)).astype(np.float32) * 2.0).cuda()
+    k = BiLstmDecoderGPU(n, fmax, m)
+    feats = torch.full((n, fmax, 20), 777.0, dtype=torch.float32, device="cuda")
+    k.forward_rows_torch(pool, rows, counts, feats, fmax)
+    one = BiLstmDecoderGPU(1, fmax, m)
+    for i in (list(range(n)) if n <= 5 else list(range(0, n, max(1, n // 24))) + [n - 1]):
+        L = int(counts[i])
+        if L:
+            want = one(pool[int(rows[i]), :L][None])[0]
+            assert torch.equal(feats[i, :L], want), i
+            with torch.no_grad():
+                ref, _ = m(pool[int(rows[i]), :L][None], m.create_new_initial_state(batch_size=1, device="cuda"))
+            assert (feats[i, :L] - ref[0]).abs().max().item() <= 2e-5
+        assert (feats[i, L:] == 777.0).all(), i
+    # float64 pool (frames as the extractor returns them), identity rows
+    p64 = pool[:n].to(torch.float64).contiguous()
+    f2 = torch.zeros_like(feats)
+    k.forward_rows_torch(p64, None, counts, f2, fmax)
+    for i in (0, 2, n - 1):
+        L = int(counts[i])
+        assert torch.equal(f2[i, :L], one(pool[i, :L][None])[0])
+    with pytest.raises(Exception):
+        k.forward_rows_torch(pool, rows, counts + fmax, feats, fmax)          # counts beyond the call's frames

@@ -102,7 +102,7 @@ def test_gated_streaming_pipeline_against_per_stream_composition(oracle):
     ecog = rng.standard_normal((S, ticks * 40, C)) * env[:, :, None]
     mean = np.full(C, 7.4)                              # between the two stretches' log band power (about 4.4 and 10.4)
     pipe = GatedStreamingPipeline(S, C, buffer_size=300, context_frames=8, channel_means=mean, vad=_ThresholdVAD(),
-                                  max_segment_frames=300)
+                                  max_segment_frames=300, asynchronous=False)      # the reference's own behaviour: the tick waits
     host = [_host_gate(C, 300, 8, 5) for _ in range(S)]
     vocoders = [oracle.decoder(model) for _ in range(S)]
     counter, n_seg = 0, 0
@@ -197,7 +197,7 @@ def test_gated_pipeline_with_the_vad_kernel_equals_the_torch_detector():
             m.classifier.weight[1] = -m.classifier.weight[0]
             m.classifier.bias.zero_()
         return m
-    kw = dict(buffer_size=300, context_frames=8, max_segment_frames=300, channel_means=mean)
+    kw = dict(buffer_size=300, context_frames=8, max_segment_frames=300, channel_means=mean, asynchronous=False)
     a = GatedStreamingPipeline(S, C, vad=detector(), **kw)
     b = GatedStreamingPipeline(S, C, vad=detector(), use_vad_kernel=False, **kw)
     assert a.vad_gpu is not None and b.vad_gpu is None
@@ -211,6 +211,149 @@ def test_gated_pipeline_with_the_vad_kernel_equals_the_torch_detector():
         for (_, _, x), (_, _, y) in zip(ga, gb):
             assert np.array_equal(x, y)
     assert 0 < n_labels < S * 30 * 4                      # the seeded detector says both things
+
+
+def _loud_quiet(rng, S, n, lo, hi, a=150, b=500):
+    env = np.ones((S, n))
+    for s in range(S):
+        t, loud = 0, bool(rng.integers(2))
+        while t < n:
+            k = int(rng.integers(a, b))
+            env[s, t:t + k] = hi if loud else lo
+            loud, t = not loud, t + k
+    return env
+
+
+def test_asynchronous_segment_synthesis_equals_the_blocking_path():
+    """The many-stream gated mode with vocoding OFF the tick path (SegmentSynthesisQueue: closing segments collected into a
+    pool, ragged decoder + ragged vocoder launch on side streams, PCM by event) against the blocking path (asynchronous=False,
+    what the reference's single stream does, units.py:531-538): per stream the same segments, in the same order, with the
+    same previous_frames and bit-identical PCM -- a stream's vocoder state carries from segment to segment in both.  Runs
+    with fewer rows per job than streams and a single lane as well, so that segments queue behind each other."""
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import GatedStreamingPipeline
+    lpcnet.load_model(synthetic_blob(0))
+    S, C, ticks = 12, 64, 90
+    rng = np.random.default_rng(77)
+    env = _loud_quiet(rng, S, ticks * 40, 20.0, 400.0, 120, 420)
+    ecog = rng.standard_normal((S, ticks * 40, C)) * env[:, :, None]
+    kw = dict(buffer_size=300, context_frames=8, channel_means=np.full(C, 7.4), vad=_ThresholdVAD(), max_segment_frames=300)
+    ref = GatedStreamingPipeline(S, C, asynchronous=False, **kw)
+    want = []
+    for k in range(ticks):
+        want += ref.push(ecog[:, k * 40:(k + 1) * 40])
+    assert len(want) >= 20 and ref.flush() == []
+    for lanes, rows in ((3, 32), (1, 2), (2, 1)):
+        pipe = GatedStreamingPipeline(S, C, asynchronous=True, n_lanes=lanes, rows_per_job=rows, **kw)
+        got, seen_pending = [], 0
+        for k in range(ticks):
+            got += pipe.push(ecog[:, k * 40:(k + 1) * 40])
+            seen_pending = max(seen_pending, pipe.queue.in_flight)
+        got += pipe.flush()
+        assert pipe.queue.in_flight == 0 and pipe.segments_closed == len(want) == len(got)
+        assert seen_pending > 0                               # ticks really returned while segments were still in flight
+        for s in range(S):                                    # per stream: same sequence (closing order), same audio
+            a = [(p, pcm) for st, p, pcm in got if st == s]
+            b = [(p, pcm) for st, p, pcm in want if st == s]
+            assert [p for p, _ in a] == [p for p, _ in b], (lanes, rows, s)
+            for (_, x), (_, y) in zip(a, b):
+                assert x.dtype == np.int16 and np.array_equal(x, y), (lanes, rows, s)
+        assert len(pipe.queue.latencies_ms) == len(got)
+        del pipe
+
+
+def test_asynchronous_queue_with_a_module_of_another_architecture():
+    """A decoder the kernels do not take (3 layers) runs as the PyTorch-ROCm module on the lane's stream: same PCM as the
+    blocking path."""
+    from dss_amd import lpcnet
+    from dss_amd.models import BidirectionalSpeechSynthesisModel
+    from dss_amd.pipeline import GatedStreamingPipeline
+    lpcnet.load_model(synthetic_blob(0))
+    S, C, ticks = 4, 64, 60
+    rng = np.random.default_rng(78)
+    ecog = rng.standard_normal((S, ticks * 40, C)) * _loud_quiet(rng, S, ticks * 40, 20.0, 400.0)[:, :, None]
+
+    def model():
+        torch.manual_seed(3)
+        return BidirectionalSpeechSynthesisModel(nb_layer=3, nb_hidden_units=24, nb_electrodes=C)
+    kw = dict(buffer_size=300, context_frames=8, channel_means=np.full(C, 7.4), vad=_ThresholdVAD(), max_segment_frames=300)
+    a = GatedStreamingPipeline(S, C, decoder=model(), asynchronous=False, **kw)
+    b = GatedStreamingPipeline(S, C, decoder=model(), asynchronous=True, **kw)
+    assert a.dec_gpu is None and b.dec_gpu is None
+    want, got = [], []
+    for k in range(ticks):
+        want += a.push(ecog[:, k * 40:(k + 1) * 40])
+        got += b.push(ecog[:, k * 40:(k + 1) * 40])
+    got += b.flush()
+    assert len(want) >= 4 and sorted((s, p) for s, p, _ in got) == sorted((s, p) for s, p, _ in want)
+    d = {(s, p): pcm for s, p, pcm in want}
+    for s, p, pcm in got:
+        assert np.array_equal(pcm, d[(s, p)])
+
+
+def test_look_alike_modules_keep_their_own_forward():
+    """fits() reads parameter names and shapes; make_kernel() also runs the module: a decoder / detector with the reference's
+    parameters but another forward (a clamp behind the head, float64 weights) is NOT swapped for the kernels."""
+    from dss_amd import decoder as D, vad as V
+    from dss_amd.models import BidirectionalSpeechSynthesisModel, UnidirectionalVoiceActivityDetector
+
+    class Clamped(BidirectionalSpeechSynthesisModel):
+        def forward(self, x, state=None):
+            y, st = super().forward(x, state)
+            return torch.clamp(y, -0.01, 0.01), st
+
+    class Scaled(UnidirectionalVoiceActivityDetector):
+        def forward(self, x, state=None):
+            return super().forward(x * 3.0, state)
+    torch.manual_seed(0)
+    plain = BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64).eval().cuda()
+    assert D.make_kernel(plain, 1, 16) is not None
+    look = Clamped(nb_layer=2, nb_hidden_units=100, nb_electrodes=64).eval().cuda()
+    assert D.fits(look)
+    with pytest.warns(RuntimeWarning, match="forward differs"):
+        assert D.make_kernel(look, 1, 16) is None
+    assert not D.fits(BidirectionalSpeechSynthesisModel(nb_layer=2, nb_hidden_units=100, nb_electrodes=64).double())
+    det = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64).eval().cuda()
+    assert V.make_kernel(det, 4) is not None
+    look = Scaled(nb_layer=2, nb_hidden_units=150, nb_electrodes=64).eval().cuda()
+    assert V.fits(look)
+    with pytest.warns(RuntimeWarning, match="forward differs"):
+        assert V.make_kernel(look, 4) is None
+    assert not V.fits(UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64).double())
+
+
+@pytest.mark.parametrize("S,W", [(257, 4), (513, 5)])
+def test_vad_kernel_two_streams_per_workgroup(S, W):
+    """Beyond 256 streams a workgroup steps two streams (the SW = 2 instantiation; an odd count leaves the last one half
+    empty): logits against torch.nn.LSTM over several packets with carried state, and reset of one stream."""
+    from dss_amd.models import UnidirectionalVoiceActivityDetector
+    from dss_amd.vad import VadLstmGPU
+    torch.manual_seed(11)
+    m = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64).eval().cuda()
+    k = VadLstmGPU(S, m)
+    state = m.create_new_initial_state(batch_size=S, device="cuda")
+    rng = np.random.default_rng(S)
+    for w in (W, 1, W):
+        z = torch.from_numpy(rng.standard_normal((S, w, 64)) * 2.0).cuda()
+        with torch.no_grad():
+            want, state = m(z.to(torch.float32), state)
+        labels, logits = k.step_torch(z, want_logits=True)
+        assert (logits - want).abs().max().item() <= 2e-5
+        sure = (want[..., 1] - want[..., 0]).abs() > 1e-4
+        assert torch.equal(labels[sure], want.argmax(dim=2).to(torch.int32)[sure])
+    h, c = k.state()
+    assert np.abs(h - state[0].cpu().numpy()).max() <= 2e-5 and np.abs(c - state[1].cpu().numpy()).max() <= 1e-4
+    k.reset(S - 1)                                          # the odd stream out, on the steps' stream
+    k.reset(2)
+    h2, c2 = k.state()
+    assert not h2[:, S - 1].any() and not c2[:, 2].any() and np.array_equal(h2[:, 3], h[:, 3])
+    state = (state[0].clone(), state[1].clone())
+    state[0][:, S - 1] = 0; state[1][:, S - 1] = 0; state[0][:, 2] = 0; state[1][:, 2] = 0
+    z = torch.from_numpy(rng.standard_normal((S, 3, 64))).cuda()
+    with torch.no_grad():
+        want, state = m(z.to(torch.float32), state)
+    _, logits = k.step_torch(z, want_logits=True)
+    assert (logits - want).abs().max().item() <= 2e-5
 
 
 @pytest.mark.parametrize("S,C,H", [(1, 5, 7), (3, 64, 150), (5, 17, 33), (2, 128, 160)])

@@ -683,3 +683,67 @@ def test_pair_kernel_is_chosen_beyond_one_utterance_per_cu(golden, model):
     assert np.array_equal(auto, one) and np.array_equal(auto, two)
     assert np.array_equal(auto[0], g["utt2_pcm"]) and np.array_equal(auto[600], g["utt2_pcm"])
     print(f"601 x {F} frames: auto {t_auto:.1f} ms, one utterance per workgroup {t_one:.1f} ms, two {t_two:.1f} ms")
+
+
+def test_lanes_share_the_decoder_slots_of_their_batch(oracle, model):
+    """dss_lpcnet_batch_create_lane: launch contexts with their own scratch on the decoder slots of one batch.  Two lanes on two
+    streams synthesise DIFFERENT slots at the same time (nothing between the launches orders them), then continue each
+    other's slots after an event: per slot the PCM is what one oracle decoder gives for the same frames in the same order.
+    More rows than the lane has, an unknown slot, a lane of a lane are refused; a parent destroyed first lives on in its lanes."""
+    import torch
+    from dss_amd import _lib
+    from dss_amd.lpcnet import LPCNetBatch
+    L = _lib.require_gpu()
+    parent = LPCNetBatch(6, 1)
+    lanes = [parent.create_lane(3, 9), parent.create_lane(3, 9)]
+    streams = [L.dss_stream_create(), L.dss_stream_create()]
+    ev = [L.dss_event_create(), L.dss_event_create()]
+    assert all(streams) and all(ev)
+    feats = {s: synthetic_features(700 + s, 20) for s in range(6)}
+    decs = {s: oracle.decoder(model) for s in range(6)}
+    pos = {s: 0 for s in range(6)}
+    rounds = [([(0, 4), (2, 9), (4, 1)], [(1, 7), (3, 2), (5, 9)]),          # lane 0 | lane 1: (slot, frames)
+              ([(1, 3), (5, 5)], [(0, 6), (4, 9), (2, 2)]),                  # the lanes swap slots
+              ([(3, 9)], [(1, 1)])]
+    for rnd in rounds:
+        outs = []
+        for li, rows in enumerate(rnd):
+            n, fmax = len(rows), max(c for _, c in rows)
+            f = np.zeros((n, fmax, 20), np.float32)
+            for k, (s, c) in enumerate(rows):
+                f[k, :c] = feats[s][pos[s]:pos[s] + c]
+            ft = torch.from_numpy(f).cuda()
+            torch.cuda.synchronize()
+            _lib.check(L.dss_stream_wait_event(streams[li], ev[1 - li]))        # the other lane's previous round touched my slots
+            pcm = lanes[li].synthesize_ragged_torch(ft, [c for _, c in rows], slots=[s for s, _ in rows], stream=streams[li])
+            _lib.check(L.dss_event_record(ev[li], streams[li]))
+            outs.append((rows, pcm, ft))
+        for li in range(2):
+            _lib.check(L.dss_stream_synchronize(streams[li]))
+        for rows, pcm, _ in outs:
+            got = pcm.cpu().numpy()
+            for k, (s, c) in enumerate(rows):
+                want = np.concatenate([decs[s].synthesize(feats[s][t]) for t in range(pos[s], pos[s] + c)])
+                assert np.array_equal(got[k, :c * 160], want), (s, c)
+                pos[s] += c
+    f = torch.zeros((4, 2, 20), dtype=torch.float32, device="cuda")
+    with pytest.raises(_lib.DssError, match="shape out of range"):
+        lanes[0].synthesize_ragged_torch(f, [1] * 4, slots=[0, 1, 2, 3])
+    with pytest.raises(_lib.DssError, match="slot 6 out of range"):
+        lanes[0].synthesize_ragged_torch(f[:1], [1], slots=[6])
+    with pytest.raises(_lib.DssError, match="not itself a lane"):
+        lanes[0].create_lane(1, 1)
+    # the parent's own handle goes first: the lanes keep its slots alive
+    L.dss_lpcnet_batch_destroy(parent._h)
+    parent._h = None
+    c = 2
+    ft = torch.from_numpy(feats[0][pos[0]:pos[0] + c][None].copy()).cuda()
+    got = lanes[1].synthesize_ragged_torch(ft, [c], slots=[0]).cpu().numpy()
+    want = np.concatenate([decs[0].synthesize(feats[0][t]) for t in range(pos[0], pos[0] + c)])
+    assert np.array_equal(got[0], want)
+    for ln in lanes:
+        ln.close()
+    for s_ in streams:
+        L.dss_stream_destroy(s_)
+    for e_ in ev:
+        L.dss_event_destroy(e_)
