@@ -19,6 +19,11 @@ import subprocess
 import sys
 import time
 
+# The gated streaming leg keeps up to 7 segment jobs in flight on side streams next to the tick's stream; ROCm maps streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share one run one after the other.  Must be set
+# before the HIP runtime initialises; an explicit setting of the caller's is respected.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "delayed-speech-synthesis_amd")
 for p in (PKG, os.path.join(ROOT, "tests")):
@@ -368,81 +373,9 @@ def main():
     # prosthesis would see it).
     latency_gated = None
     if extras:
-        from dss_amd.models import UnidirectionalVoiceActivityDetector
-        from dss_amd.pipeline import GatedStreamingPipeline
-        S, ticks, warm = 128, 260, 10                                # 10 s of stream time behind 10 warm-up ticks
-        rng = np.random.default_rng(1)
-        # loud / quiet stretches of 1 .. 4 s per stream, and a seeded detector whose two logits mirror each other, so that
-        # its decision follows the input and both labels occur (no trained checkpoint exists offline)
-        env = np.empty((S, ticks * 40))
-        for s_ in range(S):
-            t_, loud = 0, bool(rng.integers(2))
-            while t_ < env.shape[1]:
-                n_ = int(rng.integers(1000, 4000))
-                env[s_, t_:t_ + n_] = 60.0 if loud else 3.0
-                loud, t_ = not loud, t_ + n_
-        packets = [(rng.standard_normal((S, 40, 64)) * env[:, 40 * k:40 * k + 40, None]) for k in range(ticks)]
-
-        def detector():
-            torch.manual_seed(5)
-            vad = UnidirectionalVoiceActivityDetector(nb_layer=2, nb_hidden_units=150, nb_electrodes=64)
-            with torch.no_grad():
-                vad.classifier.weight[1] = -vad.classifier.weight[0]
-                vad.classifier.bias.zero_()
-            return vad
-        pct = lambda a, q: float(np.percentile(a, q)) if len(a) else None
-
-        def run(paced):
-            gp = GatedStreamingPipeline(S, 64, channel_means=np.full(64, 5.0), vad=detector(), max_segment_frames=1040)   # no segment can outgrow the 10.4 s of the leg
-            tick_ms, closing_ms, n_seg, seg_frames = [], [], 0, 0
-            t_start = time.perf_counter()
-            for k in range(ticks):
-                if paced:                                            # the amplifier's cadence; the host polls while it waits
-                    due = t_start + 0.04 * k
-                    while time.perf_counter() < due:
-                        got = gp.poll()
-                        n_seg += len(got); seg_frames += sum(len(pcm) // FRAME for _, _, pcm in got)
-                        time.sleep(0.0005)
-                if k == warm:
-                    t_meas = time.perf_counter()
-                    gp.queue.latencies_ms.clear()
-                closed_before = gp.segments_closed
-                t0 = time.perf_counter()
-                got = gp.push(packets[k])
-                ms = (time.perf_counter() - t0) * 1e3
-                n_seg += len(got); seg_frames += sum(len(pcm) // FRAME for _, _, pcm in got)
-                if k >= warm:
-                    tick_ms.append(ms)
-                    if gp.segments_closed > closed_before:
-                        closing_ms.append(ms)
-            t_ticks = time.perf_counter() - t_meas
-            got = gp.flush()
-            n_seg += len(got); seg_frames += sum(len(pcm) // FRAME for _, _, pcm in got)
-            wall = time.perf_counter() - t_meas
-            lat = list(gp.queue.latencies_ms)
-            res = {"ticks": len(tick_ms), "tick_p50_ms": pct(tick_ms, 50), "tick_p99_ms": pct(tick_ms, 99), "tick_max_ms": max(tick_ms),
-                   "ticks_that_closed_a_segment": len(closing_ms), "closing_tick_p50_ms": pct(closing_ms, 50), "closing_tick_p99_ms": pct(closing_ms, 99),
-                   "segments": n_seg, "mean_segment_frames": (seg_frames / n_seg) if n_seg else None,
-                   "segment_close_to_pcm_on_host_p50_ms": pct(lat, 50), "segment_close_to_pcm_on_host_p99_ms": pct(lat, 99),
-                   "jobs": gp.queue.jobs_launched, "ticks_wall_s": t_ticks, "wall_s_incl_drain": wall,
-                   "vad_kernel": gp.vad_gpu is not None, "decoder_kernel": gp.dec_gpu is not None, "lanes": len(gp.queue.lanes)}
-            del gp
-            return res
-        stream_s = (ticks - warm) * 0.04
-        unpaced = run(False)
-        paced = run(True)
-        latency_gated = {"config": "128 streams x 40-sample packets through HGA -> VAD LSTM(150)x2 (csrc/vad_lstm.hip, one launch) -> gate kernel -> "
-                                   "event counts on the host; segments that close are collected (one launch on the tick's stream) and decoded + vocoded "
-                                   "on side streams (ragged csrc/bilstm_decoder.hip call + ragged LPCNet launch on a lane + async PCM copy per job; "
-                                   "dss_amd/segment_queue.py), push() returns the segments finished since the last tick; seeded detector, loud / quiet "
-                                   "synthetic input",
-                         "stream_seconds": stream_s,
-                         "unpaced": unpaced, "unpaced_wall_over_stream_time": unpaced["wall_s_incl_drain"] / stream_s,
-                         "paced_40ms": paced, "paced_wall_over_stream_time": paced["wall_s_incl_drain"] / stream_s,
-                         "note": "tick_* = wall time of push() over ALL measured ticks (host packet in -> event counts read, closing "
-                                 "segments handed to the queue, finished PCM handed back); segment_close_to_pcm = submit on the closing "
-                                 "tick -> its PCM seen on the host by poll().  BENCH_r04 (vocoding on the tick path): closing ticks p50 145 ms, "
-                                 "about 21 s of wall time for these 10 s of streams."}
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gated_leg                                              # tools/gated_leg.py: the leg, shared with its stand-alone runner
+        latency_gated = gated_leg.leg()
 
     # Level 1 of the drop-in: what an UNCHANGED decode_online.py pays per 10 ms frame -- LPCNet.LPCNet().synthesize()
     # through the xiph ABI (lpcnet_synthesize: one state, one frame, host in / host out; replayed from a per-state HIP graph)

@@ -2,6 +2,8 @@
 // flight at once -- streams, events and page-locked host memory as plain handles -- without binding a HIP runtime itself.
 // (Python hosts use PyTorch-ROCm's streams and events for the same purpose; these entry points are for hosts without it
 // and for memory kinds torch does not hand out.)
+#include <algorithm>
+
 #include "dss_host.h"
 
 extern "C" void *dss_stream_create(void)
@@ -87,9 +89,31 @@ extern "C" void dss_host_free(void *p)
     if (p) hipHostFree(p);
 }
 
+// Device -> page-locked host memory as a KERNEL (16-byte stores straight into the mapped host pages), not as a DMA copy.
+// A hipMemcpyAsync queued behind a long kernel parks in a DMA-engine queue until that kernel has finished -- and every other
+// copy the process issues meanwhile, the tick's blocking packet upload included, queues up behind it there: measured, the
+// tick's 0.1 ms host-to-device copy took 137 ms while a vocoder launch with a PCM copy behind it was in flight.  A kernel
+// waits in its own stream only.
+__global__ void __launch_bounds__(256) dss_copy_out_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                           const unsigned char *__restrict__ src_tail, unsigned char *__restrict__ dst_tail,
+                                                           int tail)
+{
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) dst[k] = src[k];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 extern "C" int dss_memcpy_d2h_async(void *host_dst, const void *d_src, size_t bytes, void *hip_stream)
 {
     if (!host_dst || !d_src) { dss_set_error("null argument"); return DSS_EINVAL; }
-    DSS_HIP_CHECK(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    if (((uintptr_t)host_dst | (uintptr_t)d_src) & 15) { dss_set_error("dss_memcpy_d2h_async: both pointers must be 16-byte aligned"); return DSS_EINVAL; }
+    if (!bytes) return DSS_OK;
+    void *dev_view = nullptr;                       // the device's address of the page-locked block (fails for pageable memory)
+    DSS_HIP_CHECK(hipHostGetDevicePointer(&dev_view, host_dst, 0));
+    const size_t n16 = bytes / 16;
+    const int tail = (int)(bytes - n16 * 16);
+    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n16 + 255) / 256, 1), 512);
+    hipLaunchKernelGGL(dss_copy_out_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, (const uint4 *)d_src, (uint4 *)dev_view, n16,
+                       (const unsigned char *)d_src + n16 * 16, (unsigned char *)dev_view + n16 * 16, tail);
+    DSS_HIP_CHECK(hipGetLastError());
     return DSS_OK;
 }

@@ -186,7 +186,7 @@ class GatedStreamingPipeline(_DecoderMixin):
                  channel_means: Optional[np.ndarray] = None, channel_stds: Optional[np.ndarray] = None,
                  decoder: Optional[torch.nn.Module] = None, vad: Optional[torch.nn.Module] = None, seed: int = 0,
                  max_segment_frames: Optional[int] = None, use_vad_kernel: bool = True, use_decoder_kernel: bool = True,
-                 asynchronous: bool = True, n_lanes: int = 3, rows_per_job: int = 32):
+                 asynchronous: bool = True, n_lanes: Optional[int] = None, rows_per_job: int = 32):
         self.S, self.C, self.packet = n_streams, n_channels, packet
         self.hga = HgaExtractorGPU(n_streams, n_channels, fs=fs)
         self.decoder = self._make_decoder(n_channels, decoder, seed)

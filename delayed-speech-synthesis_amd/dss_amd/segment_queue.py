@@ -16,8 +16,10 @@ segments that closed on different streams are synthesised side by side and nothi
 ``poll()`` returns the segments finished since the last call; it never waits.
 
 Lanes: each has its own HIP stream, decoder scratch, vocoder scratch and result buffer.  ROCm maps streams onto
-``GPU_MAX_HW_QUEUES`` hardware queues (4 by default): with the tick's stream that leaves three lanes that really run
-concurrently, which is the default here.
+``GPU_MAX_HW_QUEUES`` hardware queues (4 by default) and two streams that share one run their kernels one after the other:
+a lane sharing the TICK's queue would put 140 ms of vocoder in front of a tick.  So the number of lanes defaults to
+``GPU_MAX_HW_QUEUES - 1`` (three without the variable; a host that wants more sets it before the HIP runtime starts --
+bench.py and tools/gated_leg.py use 8), at most 7.
 """
 from __future__ import annotations
 
@@ -31,6 +33,16 @@ import torch
 
 from . import _lib
 from .lpcnet import FRAME_SIZE, LPCNetBatch
+
+
+def default_lanes() -> int:
+    """One hardware queue stays the tick's own: GPU_MAX_HW_QUEUES - 1 lanes (ROCm's default of 4 queues: three), at most 7."""
+    import os
+    try:
+        q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        q = 4
+    return max(1, min(7, q - 1))
 
 
 class _Segment:
@@ -82,7 +94,7 @@ class _Lane:
 
 class SegmentSynthesisQueue:
     def __init__(self, gate, vocoder: LPCNetBatch, n_features: int, seg_cap: int, decoder_factory=None, decoder_module=None,
-                 n_lanes: int = 3, rows_per_job: int = 32, pool_rows: Optional[int] = None, n_out: int = 20):
+                 n_lanes: Optional[int] = None, rows_per_job: int = 32, pool_rows: Optional[int] = None, n_out: int = 20):
         """gate: the SpeechGateGPU whose completed segments are taken; vocoder: the LPCNetBatch with one slot per stream.
         decoder_factory(rows, frames) -> BiLstmDecoderGPU (one per lane: each owns its layer buffers), or None: then
         decoder_module (any torch module with the reference's call signature) runs row by row on the lane's stream."""
@@ -92,6 +104,8 @@ class SegmentSynthesisQueue:
         self.module = decoder_module
         if decoder_factory is None and decoder_module is None:
             raise ValueError("a decoder kernel factory or a decoder module is needed")
+        if n_lanes is None:
+            n_lanes = default_lanes()
         self.lanes = [_Lane(self._L, vocoder, decoder_factory, self.R, self.cap, self.n_out) for _ in range(int(n_lanes))]
         rows = int(pool_rows or max(2 * self.S, 4 * self.R))
         self.pool = torch.zeros((rows, self.cap, self.C), dtype=torch.float32, device="cuda")
@@ -104,6 +118,17 @@ class SegmentSynthesisQueue:
         self.latencies_ms: list = []                          # segment closed (submit) -> PCM seen on the host (poll)
         self.jobs_launched = 0
         self.segments_done = 0
+        self._warm_up()
+
+    def _warm_up(self):
+        """The first launch of the sample-rate kernels in a process loads their code object (milliseconds): pay that here, on a
+        scratch decoder, not on the tick that closes the first segment."""
+        scratch = LPCNetBatch(1, 1)
+        lane = scratch.create_lane(1, 2)
+        lane.synthesize_ragged_torch(torch.zeros((1, 2, 20), dtype=torch.float32, device="cuda"), [2], slots=[0], stream=self.lanes[0].stream)
+        _lib.check(self._L.dss_stream_synchronize(self.lanes[0].stream))
+        lane.close()
+        scratch.close()
 
     # ---- tick side ------------------------------------------------------------------------------------------
     def submit(self, streams, events, lengths, tags, tick_stream=None):

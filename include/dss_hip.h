@@ -69,6 +69,9 @@ int dss_stream_wait_event(void *hip_stream, void *event);
  * read once the copy's event has completed; 0: coherent pages. */
 void *dss_host_alloc(size_t bytes, int cached);
 void dss_host_free(void *p);
+/* Device -> page-locked host memory (from dss_host_alloc), ordered on hip_stream; both pointers 16-byte aligned.  Runs as a
+ * small kernel that stores into the mapped host pages, NOT as a DMA copy: a DMA copy queued behind a long kernel holds up
+ * every other copy of the process (the tick's packet upload) until that kernel has finished. */
 int dss_memcpy_d2h_async(void *host_dst, const void *d_src, size_t bytes, void *hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
