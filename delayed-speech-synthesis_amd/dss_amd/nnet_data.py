@@ -249,21 +249,91 @@ def kernel_fit(blob: bytes) -> dict:
     return out
 
 
-if __name__ == "__main__":
-    if len(sys.argv) not in (3, 4):
-        sys.exit("usage: python -m dss_amd.nnet_data <nnet_data.c> <out.blob> [gru_a_order: 0 (default, xiph 2021) | 1 (2019-20)]")
-    n = convert(sys.argv[1], sys.argv[2], gru_a_order=int(sys.argv[3]) if len(sys.argv) == 4 else 0)
-    print(f"wrote {sys.argv[2]}: {n} bytes")
+XIPH_CHECKS = """Before trusting a blob converted from a xiph/LPCNet tree, run these three checks IN THAT TREE (tests/golden/README.md has
+the whole recipe; DESIGN.md section 2 says why they decide whether this build answers the right program):
+  1. gcc -O2 -dM -E -Iinclude -Isrc src/nnet.c | grep -E "DOT_PROD|__SSE2__|__AVX__"
+        DOT_PROD defined => the reference's build runs the int8 arithmetic; the blob's float weights are NOT what it runs
+  2. grep -n rcp_ps src/vec_avx.h
+        a hit => that build's sigmoid / tanh use the approximate reciprocal: no unique output, no +-1 LSB claim possible
+  3. grep -n '#include "vec' src/nnet.c src/vec.h
+        which vec*.h the build really includes (generic vec.h = what the oracle and the kernels restate)"""
+
+
+def inspect_xiph_tree(src_dir: str) -> dict:
+    """What can be read off the tree nnet_data.c lies in, without a compiler: does its vec.h hand a plain x86-64 build (which
+    defines __SSE2__ but not __AVX__) to vec_avx.h, and does that header use the approximate reciprocal?
+    {"vec_h": found?, "selects_avx_on_default_x86_64": True / False / None (unknown), "condition": text, "rcp_ps": True / False / None}"""
+    import os
+    out = {"vec_h": False, "selects_avx_on_default_x86_64": None, "condition": None, "rcp_ps": None}
+    vec = os.path.join(src_dir, "vec.h")
+    if os.path.exists(vec):
+        out["vec_h"] = True
+        with open(vec, "r", errors="replace") as f:
+            lines = f.read().splitlines()
+        cond = None
+        for i, ln in enumerate(lines):
+            if re.search(r'#\s*include\s*"vec_avx\.h"', ln):
+                for j in range(i - 1, -1, -1):                     # the #if / #elif that guards it
+                    if re.match(r"\s*#\s*(if|elif|ifdef)\b", lines[j]):
+                        cond = lines[j].strip()
+                        break
+                break
+        out["condition"] = cond
+        if cond is None:
+            out["selects_avx_on_default_x86_64"] = False           # vec.h never includes vec_avx.h
+        else:
+            out["selects_avx_on_default_x86_64"] = bool(re.search(r"__SSE2?__|__SSE4|__x86_64__|__SSSE3__", cond)) and True or \
+                (False if re.search(r"__AVX", cond) else None)
+    avx = os.path.join(src_dir, "vec_avx.h")
+    if os.path.exists(avx):
+        with open(avx, "r", errors="replace") as f:
+            out["rcp_ps"] = "rcp_ps" in f.read()
+    return out
+
+
+def main(argv=None) -> int:
+    import os
+    argv = list(sys.argv[1:] if argv is None else argv)
+    i_know = "--i-know" in argv
+    argv = [a for a in argv if a != "--i-know"]
+    if len(argv) not in (2, 3):
+        print("usage: python -m dss_amd.nnet_data <nnet_data.c> <out.blob> [gru_a_order: 0 (default, xiph 2021) | 1 (2019-20)] [--i-know]",
+              file=sys.stderr)
+        return 2
+    print(XIPH_CHECKS)
+    tree = inspect_xiph_tree(os.path.dirname(os.path.abspath(argv[0])))
+    if not tree["vec_h"]:
+        print("\nNOTE: no vec.h beside " + argv[0] + ": the checks above could not even be pre-read here.  Run them in the tree the file "
+              "came from before any parity claim.")
+    else:
+        print(f"\nvec.h beside the source: vec_avx.h is included under `{tree['condition']}`" if tree["condition"] else
+              "\nvec.h beside the source never includes vec_avx.h (generic path)")
+        if tree["rcp_ps"]:
+            print("vec_avx.h uses _mm*_rcp_ps (approximate reciprocal): a build that takes it has no unique output")
+        if tree["selects_avx_on_default_x86_64"] and not i_know:
+            print("\nREFUSED: this tree hands a plain x86-64 build (__SSE2__ is always defined there) to vec_avx.h, i.e. to DOT_PROD / int8 "
+                  "arithmetic -- not what the blob, the oracle and the kernels implement.  Run check 1 to be sure; if the reference's build "
+                  "really compiles the generic path (or you want the float blob anyway), repeat with --i-know.", file=sys.stderr)
+            return 3
+        if tree["selects_avx_on_default_x86_64"] is None:
+            print("could not tell from vec.h's condition whether a plain x86-64 build takes vec_avx.h: run check 1")
+    n = convert(argv[0], argv[1], gru_a_order=int(argv[2]) if len(argv) == 3 else 0)
+    print(f"wrote {argv[1]}: {n} bytes")
     from .lpcnet_weights import blob_source_branches
-    with open(sys.argv[2], "rb") as f:
+    with open(argv[1], "rb") as f:
         br = blob_source_branches(f.read(96))
     print("source branches: " + {1: "float only (no #ifdef DOT_PROD pairs)", 3: "float AND DOT_PROD (int8) -- the blob holds the float "
-          "branch, the DOT_PROD arrays are in " + sys.argv[2] + ".dotprod.npz; check which one the reference's build compiles "
-          "(gcc -dM -E on its vec.h: DOT_PROD defined?) before trusting parity"}.get(br, str(br)))
+          "branch, the DOT_PROD arrays are in " + argv[1] + ".dotprod.npz; check which one the reference's build compiles "
+          "(check 1 above) before trusting parity"}.get(br, str(br)))
     try:
-        with open(sys.argv[2], "rb") as f:
+        with open(argv[1], "rb") as f:
             fit = kernel_fit(f.read())
         print(f"sample-rate kernel: {fit['kernel']}; z/r blocks per row group <= {fit['zr_blocks_max']}, h blocks <= "
               f"{fit['h_blocks_max']}, LDS image {fit['lds_bytes']} B")
     except Exception as e:           # the library may not be built on the machine that converts
         print(f"(kernel fit not checked: {e})")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -7,8 +7,10 @@ decode_online.py:65-97 builds, in this order, in front of the filters
     SelectElectrodesOverSpeechAreas    local/common.py:35-58    data[:, speech_grid_mapping]    (-> 64 channels)
 and behind the log power
     ZScoreNormalization                local/common.py:367-376  (data - means) / stds
-The reference's local/common.py cannot be imported here (it needs h5py, which the image lacks), and it has no test
-or fixture for these classes, so this restatement is pinned by the closed-form checks in tests/test_cpu_host.py.
+Pinned against the reference's OWN classes: tests/golden/ecog_chain.npz holds every stage of that chain as
+/root/reference/local/common.py computed it on a seeded 129-column packet (oracle/make_golden.py gen_common imports the file
+as it lies), and tests/test_cpu_host.py compares this restatement with it bit for bit, beside the closed-form checks of
+rounds 1-4.
 The objects expose the attribute names of the reference classes (grid_mapping, selection_masks_application,
 selection_masks_computation, speech_grid_mapping): the product recognises decode_online.py's chain through them.
 The channel tables are the product's data module (dss_amd/electrodes.py), i.e. the constants of common.py:21-28,42-48.

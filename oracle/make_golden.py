@@ -18,6 +18,12 @@ scipy.signal.iirfilter(8, band/(fs/2), btype, ftype='butter', output='sos'), whi
 construct_iir_filter resolves that request to.  [UNVERIFIED against mne itself -- recorded in
 tests/golden/README.md]
 
+  * local/common.py -- imported; VoiceActivityDetectionSmoothing / SpeechSegmentHistory (common.py:106-215) and
+    SelectElectrodesFromBothGrids / CommonAverageReferencing / SelectElectrodesOverSpeechAreas / ZScoreNormalization
+    (common.py:16-58,308-376) give gate.npz and ecog_chain.npz.  The file's first line imports h5py, which the image lacks and
+    which only save_data_to_hdf (common.py:387) uses: the name is bound to a placeholder that RAISES on any attribute access
+    (see import_reference_common), and the script asserts it was never touched.
+
 LPCNet: there is no reference implementation to run (empty submodule), so lpcnet_*.npz fixtures are
 SELF-generated from this repo's oracle (oracle/liboracle.so) and say so in their `provenance` field.
 They pin the oracle against regressions; they do not pin it against xiph.
@@ -163,7 +169,120 @@ def gen_lpcnet():
     print("lpcnet:", {k: v.shape for k, v in out.items() if k.endswith("_pcm")})
 
 
+class _Untouched:
+    """Placeholder under the name of a package the image lacks.  Any attribute access is an error: the fixtures below are
+    valid only if the reference classes that produce them never reach into it."""
+
+    def __init__(self, name):
+        object.__setattr__(self, "_name", name)
+        object.__setattr__(self, "touched", [])
+
+    def __getattr__(self, attr):
+        if attr.startswith("__"):                         # the import machinery looks at __spec__, __path__ ...
+            raise AttributeError(attr)
+        self.touched.append(attr)
+        raise AssertionError(f"the reference touched {self._name}.{attr} while generating fixtures")
+
+
+def import_reference_common():
+    """Import /root/reference/local/common.py as it lies.  Its first line is `import h5py` (common.py:1), which this image does
+    not have; h5py is used exactly once, in save_data_to_hdf (common.py:387), which nothing here calls.  The name is bound to
+    an object that raises on ANY use, so a fixture cannot silently depend on a stand-in."""
+    import importlib
+    sys.path.insert(0, "/root/reference")
+    placeholder = None
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        placeholder = _Untouched("h5py")
+        sys.modules["h5py"] = placeholder
+    common = importlib.import_module("local.common")
+    return common, placeholder
+
+
+def gen_common():
+    """Row f4 / f1 fixtures from the reference's own numpy classes (local/common.py:16-58, 106-215, 308-376)."""
+    common, placeholder = import_reference_common()
+    # ---- f4: VoiceActivityDetectionSmoothing + SpeechSegmentHistory, chained as FilterSpeechSegments.process does (units.py:436-447)
+    out = {}
+    cases = [  # (features, ring size, segment context, smoothing context, pushes, label flip probability)
+        (64, 2000, 50, 5, 700, 0.015),       # decode_online.py:115-121
+        (5, 37, 3, 2, 200, 0.08),            # a ring that wraps many times
+        (7, 16, 0, 0, 150, 0.3),             # context 0 (the stop = write pointer - 1 branch), no smoothing
+        (3, 23, 4, 1, 200, 0.02),            # speech runs longer than the ring (the classes' modulo arithmetic)
+        (4, 64, 10, 5, 120, 0.05),
+    ]
+    for ci, (C, N, ctx, sm, pushes, p_flip) in enumerate(cases):
+        rng = np.random.default_rng(4000 + ci)
+        smoothing = common.VoiceActivityDetectionSmoothing(nb_features=C, context_frames=sm)
+        history = common.SpeechSegmentHistory(nb_features=C, buffer_size=N, context=ctx)
+        frames_all, labels_all, sizes, seg_push, seg_len, seg_rows, n_speech = [], [], [], [], [], [], []
+        state = 0
+        for k in range(pushes):
+            W = int(rng.integers(1, 8))
+            frames = (rng.standard_normal((W, C)) * 3.0).astype(np.float32).astype(np.float64)   # float32-valued: stored as float32
+            labels = np.zeros(W, dtype=np.int64)
+            for i in range(W):
+                if rng.random() < p_flip:
+                    state = 1 - state
+                labels[i] = state
+            data, smoothed = smoothing.insert(frames, labels)
+            segments = history.insert(data, smoothed)
+            n_speech.append(int(np.count_nonzero(smoothed)))
+            for seg in segments:
+                assert seg.dtype == np.float32
+                seg_push.append(k); seg_len.append(len(seg)); seg_rows.append(np.asarray(seg))
+            frames_all.append(frames); labels_all.append(labels); sizes.append(W)
+        assert len(seg_len) >= 3, (ci, len(seg_len))
+        out[f"case{ci}_params"] = np.array([C, N, ctx, sm], dtype=np.int32)
+        out[f"case{ci}_sizes"] = np.array(sizes, dtype=np.int32)
+        out[f"case{ci}_frames"] = np.concatenate(frames_all, axis=0).astype(np.float32)
+        out[f"case{ci}_labels"] = np.concatenate(labels_all).astype(np.int8)
+        out[f"case{ci}_speech_per_push"] = np.array(n_speech, dtype=np.int32)
+        out[f"case{ci}_seg_push"] = np.array(seg_push, dtype=np.int32)
+        out[f"case{ci}_seg_len"] = np.array(seg_len, dtype=np.int32)
+        out[f"case{ci}_seg_rows"] = np.concatenate(seg_rows, axis=0) if seg_rows else np.zeros((0, C), np.float32)
+    out["n_cases"] = np.array([len(cases)], dtype=np.int32)
+    np.savez_compressed(os.path.join(GOLD, "gate.npz"), **out)
+    print("gate:", {f"case{ci}": int(out[f"case{ci}_seg_len"].size) for ci in range(len(cases))}, "segments")
+
+    # ---- f1: the transform chain of decode_online.py:65-97, objects built exactly as configure_feature_transforms builds them
+    rng = np.random.default_rng(5000)
+    sel_both = common.SelectElectrodesFromBothGrids()
+    speech_grid = np.flip(np.arange(64, dtype=np.int16).reshape((8, 8)) + 1, axis=0)
+    motor_grid = np.flip(np.arange(64, dtype=np.int16).reshape((8, 8)) + 65, axis=0)
+    layout = np.arange(128) + 1
+    car = common.CommonAverageReferencing(exclude_channels=[19, 38, 48, 52], grids=[speech_grid, motor_grid], layout=layout)
+    sel_speech = common.SelectElectrodesOverSpeechAreas()
+    raw = rng.standard_normal((80, 129)) * 40.0 + rng.standard_normal((1, 129)) * 15.0      # two 40-sample packets, 129 columns (units.py:78-82)
+    a = sel_both(raw)
+    b = car(a)
+    c = sel_speech(b)
+    means = rng.standard_normal(128) * 2.0 + 5.0
+    stds = rng.random(128) + 0.5
+    zs = common.ZScoreNormalization(channel_means=sel_speech(means.reshape((1, -1))), channel_stds=sel_speech(stds.reshape((1, -1))))
+    frames = rng.standard_normal((9, 64)) * 3.0 + 5.0
+    ec = {"raw": raw, "after_select_both": a, "after_car": b, "after_select_speech": c,
+          "grid_mapping": np.array(sel_both.grid_mapping, dtype=np.int32),
+          "speech_grid_mapping": np.asarray(sel_speech.speech_grid_mapping, dtype=np.int32),
+          "masks_application": np.stack(car.selection_masks_application), "masks_computation": np.stack(car.selection_masks_computation),
+          "exclude_channels": np.array([19, 38, 48, 52], dtype=np.int32),
+          "zs_means_128": means, "zs_stds_128": stds, "zs_means": np.asarray(zs.channel_means), "zs_stds": np.asarray(zs.channel_stds),
+          "zs_in": frames, "zs_out": zs(frames)}
+    np.savez_compressed(os.path.join(GOLD, "ecog_chain.npz"), **ec)
+    print("ecog_chain:", c.shape, ec["zs_out"].shape)
+    if placeholder is not None:
+        assert not placeholder.touched, placeholder.touched
+        print("h5py placeholder untouched (reference common.py imports it on line 1 and uses it only in save_data_to_hdf)")
+
+
 if __name__ == "__main__":
-    gen_hga()
-    gen_models()
-    gen_lpcnet()
+    which = sys.argv[1:] or ["hga", "models", "lpcnet", "common"]
+    if "hga" in which:
+        gen_hga()
+    if "models" in which:
+        gen_models()
+    if "lpcnet" in which:
+        gen_lpcnet()
+    if "common" in which:
+        gen_common()

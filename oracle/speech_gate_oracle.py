@@ -12,8 +12,11 @@ One object = one stream.  It restates, frame by frame and in plain Python/numpy,
              [stop - 2*context - speech_count, stop) modulo N is emitted (stop = write pointer, or write pointer - 1 when
              context == 0) and both counters restart
 
-Pinned by the hand-derived known answers in tests/test_cpu_local.py (the reference has no test or fixture for these
-classes, and reference local/common.py cannot be imported here: it needs h5py, which the image lacks).
+Pinned against the reference's OWN classes: tests/golden/gate.npz holds what VoiceActivityDetectionSmoothing +
+SpeechSegmentHistory of /root/reference/local/common.py returned for seeded label runs in five configurations (rings that
+wrap, context 0, runs longer than the ring; oracle/make_golden.py gen_common imports the file as it lies), and
+tests/test_oracle_gate.py replays them through this restatement bit for bit; the hand-derived known answers of rounds 1-4
+stay beside them.
 """
 import numpy as np
 

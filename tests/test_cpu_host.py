@@ -121,6 +121,42 @@ def test_electrode_tables_and_frontend_description():
     assert np.array_equal(got, want)                                # bit-identical, including the summation order
 
 
+def test_transform_chain_against_the_reference_classes(golden):
+    """tests/golden/ecog_chain.npz = every stage of decode_online.py:65-97's chain as the reference's OWN classes computed it
+    (SelectElectrodesFromBothGrids, CommonAverageReferencing, SelectElectrodesOverSpeechAreas, ZScoreNormalization of
+    /root/reference/local/common.py, objects built as configure_feature_transforms builds them; oracle/make_golden.py).  The
+    CPU restatement, the shipped channel tables and the GPU front end's description reproduce it bit for bit."""
+    from dss_amd import electrodes as E
+    from ecog_chain_oracle import ZScore, reference_chain
+    g = golden("ecog_chain.npz")
+    both, car, speech = reference_chain()
+    raw = g["raw"]
+    assert raw.shape == (80, 129)
+    assert np.array_equal(np.asarray(both.grid_mapping), g["grid_mapping"]) and tuple(g["grid_mapping"]) == E.GRID_COLUMNS
+    assert np.array_equal(speech.speech_grid_mapping, g["speech_grid_mapping"])
+    assert np.array_equal(E.speech_channels_zero_based(), g["speech_grid_mapping"]) and tuple(g["exclude_channels"]) == E.BAD_CHANNELS
+    assert np.array_equal(np.stack(car.selection_masks_application), g["masks_application"])
+    assert np.array_equal(np.stack(car.selection_masks_computation), g["masks_computation"])
+    a = both(raw)
+    b = car(a)
+    c = speech(b)
+    assert np.array_equal(a, g["after_select_both"]) and np.array_equal(b, g["after_car"]) and np.array_equal(c, g["after_select_speech"])
+    # the front end's description (what csrc/hga_kernels.hip hga_frontend_kernel executes): a sequential sum per grid
+    src, gof, comp = E.reference_frontend()
+    got = np.empty_like(c)
+    for ch in range(64):
+        acc = np.zeros(len(raw))
+        for col in comp[gof[ch]]:
+            acc = acc + raw[:, col]
+        got[:, ch] = raw[:, src[ch]] - acc / len(comp[gof[ch]])
+    assert np.array_equal(got, g["after_select_speech"])
+    # ZScoreNormalization, statistics selected as decode_online.py:94-95 selects them
+    zs = ZScore(speech(g["zs_means_128"].reshape((1, -1))), speech(g["zs_stds_128"].reshape((1, -1))))
+    assert np.array_equal(zs.channel_means, g["zs_means"]) and np.array_equal(zs.channel_stds, g["zs_stds"])
+    assert np.array_equal(zs(g["zs_in"]), g["zs_out"])
+    assert np.array_equal((g["zs_in"] - g["zs_means"]) / g["zs_stds"], g["zs_out"])      # the two IEEE operations dss_hga_set_zscore applies
+
+
 def test_shipped_filter_tables_are_what_scipy_designs_here(golden):
     from dss_amd import hga
     g = golden("hga_filters.npz")

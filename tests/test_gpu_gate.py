@@ -50,6 +50,28 @@ def test_gate_matches_numpy_rings_bit_exact(C, N, ctx, sm_ctx):
     assert gate.frames_seen(0) > 0
 
 
+def test_gate_against_the_reference_classes(golden):
+    """tests/golden/gate.npz: what VoiceActivityDetectionSmoothing + SpeechSegmentHistory of the reference's own
+    local/common.py returned (oracle/make_golden.py) -- the HIP gate replays every case bit for bit, each case on stream 1 of
+    a 3-stream gate whose other streams see other data (a stream's rings are its own)."""
+    from dss_amd.gate import SpeechGateGPU
+    from test_oracle_gate import replay_gate_fixture
+    g = golden("gate.npz")
+    for ci in range(int(g["n_cases"][0])):
+        C, N, ctx, sm = (int(v) for v in g[f"case{ci}_params"])
+        gate = SpeechGateGPU(3, C, N, ctx, sm, 0.6, max_frames=8)
+        rng = np.random.default_rng(ci)
+
+        def push(frames, labels):
+            W = len(labels)
+            f = rng.standard_normal((3, W, C))
+            lab = rng.integers(0, 2, (3, W))
+            f[1], lab[1] = frames, labels
+            segs, n_speech = gate.push(f, lab)
+            return segs[1], int(n_speech[1])
+        replay_gate_fixture(g, ci, push)
+
+
 def test_gate_reset_one_stream_and_errors():
     from dss_amd import _lib
     from dss_amd.gate import SpeechGateGPU

@@ -210,3 +210,29 @@ def test_raw_packets_and_zscore_in_one_launch(golden):
     e5.set_zscore(mean[:5], std[:5])
     z5 = e5.extract_torch(torch.from_numpy(x5[None]).cuda())
     assert torch.equal(z5, (p5 - torch.from_numpy(mean[:5]).cuda()) / torch.from_numpy(std[:5]).cuda())
+
+
+def test_front_end_and_zscore_against_the_reference_classes(golden):
+    """tests/golden/ecog_chain.npz (the reference's own pre/post transform classes, oracle/make_golden.py): raw 129-column
+    packets through the GPU front end + extractor give, bit for bit, the frames the extractor gives on the reference's
+    `after_select_speech` columns (the plain extractor is pinned by hga_frames.npz), packet by packet with carried state; the
+    z-score epilogue with the reference's selected statistics equals ZScoreNormalization's two operations on those frames."""
+    from dss_amd.electrodes import reference_frontend
+    from dss_amd.hga import HgaExtractorGPU
+    g = golden("ecog_chain.npz")
+    raw, pre = g["raw"], g["after_select_speech"]
+    fe = HgaExtractorGPU(1, 64, filters=_filters(golden))
+    fe.set_frontend(129, *reference_frontend())
+    plain = HgaExtractorGPU(1, 64, filters=_filters(golden))
+    frames = []
+    for a in (0, 40):
+        got = fe.extract_raw(raw[None, a:a + 40])
+        want = plain.extract(pre[None, a:a + 40])
+        assert got.shape == want.shape and got.shape[1] == (1 if a == 0 else 4) and np.array_equal(got, want)
+        frames.append(want[0])
+    frames = np.concatenate(frames)
+    z = HgaExtractorGPU(1, 64, filters=_filters(golden))
+    z.set_frontend(129, *reference_frontend())
+    z.set_zscore(g["zs_means"].reshape(-1), g["zs_stds"].reshape(-1))
+    got = np.concatenate([z.extract_raw(raw[None, a:a + 40])[0] for a in (0, 40)])
+    assert np.array_equal(got, (frames - g["zs_means"]) / g["zs_stds"])

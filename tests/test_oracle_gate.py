@@ -1,5 +1,6 @@
-"""The speech-gate oracle (oracle/speech_gate_oracle.py) against known answers derived by hand from the rules of
-reference local/common.py:106-215 (the reference has no test or fixture for these classes)."""
+"""The speech-gate oracle (oracle/speech_gate_oracle.py) against (a) what the reference's own classes returned
+(tests/golden/gate.npz: VoiceActivityDetectionSmoothing + SpeechSegmentHistory of /root/reference/local/common.py:106-215, run by
+oracle/make_golden.py) and (b) known answers derived by hand from their rules."""
 import os
 import sys
 
@@ -42,3 +43,41 @@ def test_smoothing_and_history_rules_one_at_a_time():
     segs, _ = h.push(ramp[12:24], np.array([1] * 6 + [0] * 6, dtype=bool))
     assert segs[0][:, 0].tolist() == list(range(10, 20))
     assert h.frames_seen == 24
+
+
+def replay_gate_fixture(g, ci, push):
+    """Feed case `ci` of tests/golden/gate.npz, push by push, to push(frames, labels) -> (segments, speech frames) and compare
+    with what the reference classes returned.  Shared with tests/test_gpu_gate.py."""
+    C, N, ctx, sm = (int(v) for v in g[f"case{ci}_params"])
+    sizes, frames, labels = g[f"case{ci}_sizes"], g[f"case{ci}_frames"].astype(np.float64), g[f"case{ci}_labels"]
+    seg_push, seg_len, seg_rows = g[f"case{ci}_seg_push"], g[f"case{ci}_seg_len"], g[f"case{ci}_seg_rows"]
+    want_speech = g[f"case{ci}_speech_per_push"]
+    assert frames.shape == (int(sizes.sum()), C) and seg_rows.shape == (int(seg_len.sum()), C) and seg_rows.dtype == np.float32
+    pos, seg_i, row0 = 0, 0, 0
+    for k, W in enumerate(sizes):
+        segs, n_speech = push(frames[pos:pos + W], labels[pos:pos + W].astype(np.int64))
+        pos += int(W)
+        assert n_speech == int(want_speech[k]), (ci, k)
+        for seg in segs:
+            assert seg_i < len(seg_push) and int(seg_push[seg_i]) == k, (ci, k, "a segment the reference did not emit here")
+            L = int(seg_len[seg_i])
+            assert seg.dtype == np.float32 and seg.shape == (L, C) and np.array_equal(seg, seg_rows[row0:row0 + L]), (ci, k)
+            seg_i, row0 = seg_i + 1, row0 + L
+        assert seg_i == int(np.searchsorted(seg_push, k, side="right")), (ci, k, "a segment of the reference is missing")
+    assert seg_i == len(seg_push)
+    return (C, N, ctx, sm), len(seg_push)
+
+
+def test_gate_oracle_against_the_reference_classes(golden):
+    from speech_gate_oracle import SpeechGateOracle
+    g = golden("gate.npz")
+    total = 0
+    for ci in range(int(g["n_cases"][0])):
+        C, N, ctx, sm = (int(v) for v in g[f"case{ci}_params"])
+        gate = SpeechGateOracle(C, N, ctx, sm)
+        total += replay_gate_fixture(g, ci, gate.push)[1]
+    assert total > 100
+    # the cases the fixture is meant to hold: a ring that wraps (segment count x length far beyond N), context 0, and a run
+    # longer than its ring (the emitted "segment" then has fewer rows than the run: the classes' modulo arithmetic)
+    assert int(g["case1_seg_len"].sum()) > 5 * 37 and int(g["case2_params"][2]) == 0
+    assert int(g["case3_seg_len"].max()) < 23
