@@ -333,8 +333,15 @@ static void build_fast_layout(const BlobView &v, int NA, FastLayout &F)
     const int zr17 = std::max(cnt[order_zr[16]], cnt[G + order_zr[16]]);      // heaviest group that lands on waves 0..3
     const bool plain = zmax <= DSS_ZRC && zr17 <= 8 && hmax <= DSS_HC;
     const int zr_cap = (plain && zmax > 10) ? DSS_ZRC : 10;
-    static const int rank_wave_h[6] = {0, 1, 3, 2, 5, 4};
+    int rank_wave_h[6] = {0, 1, 3, 2, 5, 4};
     static const int rank_wave_zr[6] = {4, 5, 2, 3, 1, 0};
+    if (const char *e = getenv("DSS_RANK_WAVE_H")) {        // development switch (A/B timing of the h-chain assignment): a permutation of 0..5
+        int p[6], seen = 0;
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &p[0], &p[1], &p[2], &p[3], &p[4], &p[5]) == 6) {
+            for (int k = 0; k < 6; ++k) if (p[k] >= 0 && p[k] < 6) seen |= 1 << p[k];
+            if (seen == 63) for (int k = 0; k < 6; ++k) rank_wave_h[k] = p[k];
+        }
+    }
     std::vector<int> grp_h(G, 0), grp_zr(G, 0);
     std::vector<int> &unit_of = F.unit_of, &unit_h = F.unit_h, &wave_nh = F.wave_nh, &grp_hoff = F.grp_hoff, &wave_nzr = F.wave_nzr, &wave_nzt = F.wave_nzt;
     unit_of.assign(NA, 0); unit_h.assign(NA, 0); wave_nh.assign(8, 0); grp_hoff.assign(G, 0); wave_nzr.assign(8, 0); wave_nzt.assign(8, 0);

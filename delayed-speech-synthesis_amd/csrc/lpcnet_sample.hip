@@ -69,14 +69,16 @@
 // barrier B.  "Barrier C" as an LDS word polled by the dual-FC waves was slower than the barrier (the polls take issue slots
 // and LDS cycles from the relay waves on the same SIMDs).  One state read ahead is not enough for the in-place products: the
 // LDS answers in 50+ cycles while the six GRU A waves run their h chains, so DSS_GBG_MUL keeps several pairs of reads in flight.
+// (round 5: 80 / 104 / 104 / 96 -- a shorter on-the-fly segment now that the GRU A waves' address arithmetic is lighter; same-box
+//  A/B against 96 / 96 / 96 / 96: 38.3 vs 38.5 ms.  80/96/112 the same, 64/96/128, 80/96/128 and 96/96/112 slower: 38.9 / 41.4 / 40.9)
 #ifndef GB1
-#define GB1 96
+#define GB1 80
 #endif
 #ifndef GB2
-#define GB2 96
+#define GB2 104
 #endif
 #ifndef GB3
-#define GB3 96
+#define GB3 104
 #endif
 #define GB4 (NA - GB1 - GB2 - GB3)
 #ifndef DSS_SPEC_WAVE
@@ -101,8 +103,14 @@
 static_assert(GB4 <= GB2, "segment 4's products reuse segment 2's registers");
 static_assert(GB1 % 16 == 0 && GB2 % 8 == 0 && GB3 % 8 == 0 && GB4R % 8 == 0 && GB4H % 8 == 0 && GB4H >= 0 && GB4R > 0, "segment sizes");
 struct SampleLds {
-    float state_a[2][NA + 4];             // double-buffered GRU A state; "column 96" of either buffer is four zeros: the
-                                          //   input of the h-gate slots a row group does not use (see DSS_H_CHAIN)
+    float state_a[2][NA + 4];             // GRU A state; "column 96" is four zeros: the input of the h-gate slots a row group
+                                          //   does not use (see DSS_H_CHAIN).  The state is WRITTEN between barriers D and B and
+                                          //   READ between B and C (h chains, z/r products, GRU B), so one buffer is enough -- and
+                                          //   makes every block column's LDS address `column * 16 + constant`: the constant goes
+                                          //   into the instruction's offset field and a column costs one VALU instruction (an SDWA
+                                          //   shift of its byte) instead of 2.25 (round 5; DSS_NEW / DSS_OLD below).  Only the
+                                          //   extended paths read the OLD state while the new one is written (z/r tail blocks,
+                                          //   between D and B): that instantiation keeps both buffers.
     float gb_wrec[NB * NB3];              // GRU B recurrent weights [16][48]
     float tansig[208];
     float ulaw2lin[256];
@@ -265,6 +273,10 @@ struct SampleLds {
 //   waves 4..5  no dual-FC, all Z slots -- the host gives them the row groups with the most z/r blocks.
 // Keeping the two apart is what keeps either under the 256-VGPR budget without spill reloads in the sample loop.
 // =====================================================================================================
+// which of L.state_a's buffers holds the state being written / read for sample parity `cur` (see SampleLds::state_a)
+#define DSS_NEW(cur) (EXT ? ((cur) ^ 1) : 0)
+#define DSS_OLD(cur) (EXT ? (cur) : 0)
+
 template <bool TRACE, bool STAMP, int Z, bool HAS_FC, bool EXT>
 __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const DssModelDev &m, const DssBatchDev &b,
                                            int n_frames, int utt, int slot, int nf, int fc0, int tid, int wave, int lane,
@@ -390,7 +402,7 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                                               (tid >> 3) * 2 * DSS_ZR_TAIL;
                     const char *tz = reinterpret_cast<const char *>(hblk_lds + toff[0]) + (lane & 7) * 16;
                     const char *tr = reinterpret_cast<const char *>(hblk_lds + toff[1]) + (lane & 7) * 16;
-                    const char *xb = reinterpret_cast<const char *>(L.state_a[cur]);
+                    const char *xb = reinterpret_cast<const char *>(L.state_a[DSS_OLD(cur)]);
                     unsigned cz = tc[0], cr = tc[DSS_ZR_TAIL];        // the columns of a slot are read one trip ahead
                     for (int s = 0; s < nzt; ++s) {
                         const unsigned czn = tc[s + 1], crn = tc[DSS_ZR_TAIL + s + 1];   // (one byte past a row: unused)
@@ -411,14 +423,14 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
                 float h = ahv * r + gh;
                 h = dss_tanh_approx(L.tansig, h);
                 st = z * st + (1 - z) * h;
-                L.state_a[cur ^ 1][unit] = st;
+                L.state_a[DSS_NEW(cur)][unit] = st;
                 if (STAMP) { asm volatile("" :: "v"(st)); const unsigned t = DSS_NOW(); sa[3] += t - ta; ta = t; }
             }
             __syncthreads();                                                        // barrier B
             if (STAMP) { const unsigned t = DSS_NOW(); sa[4] += t - ta; ta = t; }
             else if (DSS_RELAY_STAMP) ta = DSS_NOW();
-            DSS_H_CHAIN(L.state_a[cur ^ 1])                      // next sample's h chain, under GRU B
-            DSS_ZR_PRODUCTS(L.state_a[cur ^ 1])                  // ... and its z/r block products (sums come later)
+            DSS_H_CHAIN(L.state_a[DSS_NEW(cur)])                      // next sample's h chain, under GRU B
+            DSS_ZR_PRODUCTS(L.state_a[DSS_NEW(cur)])                  // ... and its z/r block products (sums come later)
             if (wave == DSS_SPEC_WAVE || wave < 2) {
                 // Speculation over all 256 possible excitation values of THIS sample, one candidate per lane of wave DSS_SPEC_WAVE
                 // (candidates 64..127), of waves 0, 1, which have the lightest B..C load of the dual-FC waves (128..255),
@@ -559,7 +571,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                     __syncthreads();                                                    // barrier A (first sample only)
                 }
                 __syncthreads();                                                        // barrier B
-                const float *an = L.state_a[cur ^ 1];
+                const float *an = L.state_a[DSS_NEW(cur)];
                 unsigned t6 = 0;
                 if (RS) t6 = DSS_NOW();
 #if DSS_RELAY_MASK
@@ -695,7 +707,7 @@ lpcnet_sample_kernel(DssModelDev m, DssBatchDev b, int n_frames, short *__restri
                 else if (RS) t_prev = DSS_NOW();
                 // While wave 6 runs segment 1, this wave forms the products of segment 2 (weights from L2); while wave 6 sums
                 // segment 3, those of segment 4's first GB4R inputs into the same registers.  Its own part of the chain is sums only.
-                const float *an = L.state_a[cur ^ 1];
+                const float *an = L.state_a[DSS_NEW(cur)];
 #if DSS_RELAY_MASK
                 if (lane < NB3) {
 #endif
