@@ -429,7 +429,7 @@ def main():
     # process, so they come from the committed rocprofv3 --pmc passes of this same command (profiles/), and are quoted
     # only for the workload they were taken on
     traffic, counters = None, None
-    tag = {256: "r4_b256", 1024: "r4_b1024"}.get(B)
+    tag = {256: "r5_b256", 1024: "r5_b1024"}.get(B)
     try:
         with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
             traffic = float(json.load(f)["hbm_bytes_per_launch_corrected"]) / 1e9          # GB per launch
