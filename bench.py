@@ -72,6 +72,35 @@ def _hga_job(args):
     return n * 1.04, time.time() - t0
 
 
+def _hga_ref_job(args):
+    """The same trials through the REFERENCE's own code: oracle/_ref/hga_optimized*.so -- extensions/hga/hga_optimized.pyx compiled
+    unmodified in the build container (oracle/Makefile ref; it travels with the snapshot) -- driven as HighGammaExtractor.extract_features
+    drives it (local/units.py:145-161): scipy.signal.sosfilt x 2 with carried state, WarmStartFrameBuffer.insert, compute_log_power_features."""
+    seed, n = args
+    import numpy as np
+    from scipy.signal import sosfilt
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+    import hga_optimized as ref
+    from dss_amd.hga import reference_filters
+    from dss_amd.synthetic import synthetic_ecog
+    hg, fh, zi_hg, zi_fh = reference_filters(1000)
+    xs = [synthetic_ecog(seed + k, 1040, 64) for k in range(n)]
+    t0 = time.time()
+    for x in xs:                                   # a fresh extractor per trial (prepare_corpus.py:147-176)
+        fb = ref.WarmStartFrameBuffer(frame_length=0.05, frame_shift=0.01, fs=1000, nb_channels=64)
+        s_hg = np.repeat(zi_hg, 64, axis=-1).reshape([zi_hg.shape[0], zi_hg.shape[1], -1])      # units.py:131-132
+        s_fh = np.repeat(zi_fh, 64, axis=-1).reshape([zi_fh.shape[0], zi_fh.shape[1], -1])
+        y, s_hg = sosfilt(hg, x, axis=0, zi=s_hg)
+        y, s_fh = sosfilt(fh, y, axis=0, zi=s_fh)
+        np.asarray(ref.compute_log_power_features(fb.insert(y), 1000, 0.05, 0.01))
+    return n * 1.04, time.time() - t0
+
+
+def _have_hga_ref():
+    import glob
+    return bool(glob.glob(os.path.join(ROOT, "oracle", "_ref", "hga_optimized*.so")))
+
+
 def cpu_baseline(utt_per_core=2):
     """LPCNet and HGA on the GPU box's host cores: `cores`-process pool (the reference's pattern) and ONE core.
     Pool figures = total work / wall time of the pool.map call, for both legs (a figure built from the jobs' own spans moved
@@ -97,6 +126,20 @@ def cpu_baseline(utt_per_core=2):
         t0 = time.time()
         hga_res = pool.map(_hga_job, [(1000 + 8 * j, 8) for j in range(2 * cores)], chunksize=1)
         dth = time.time() - t0
+        hga_ref = None
+        if _have_hga_ref():                                         # the reference's OWN extension module, same trials
+            try:
+                pool.map(_hga_ref_job, [(900, 1)] * cores)
+                t0 = time.time()
+                ref_res = pool.map(_hga_ref_job, [(1000 + 8 * j, 8) for j in range(2 * cores)], chunksize=1)
+                dtr = time.time() - t0
+                sec_r, t_r = _hga_ref_job((2000, 8))
+                hga_ref = {"value": sum(r[0] for r in ref_res) / dtr, "unit": "stream-seconds/s (64 ch @ 1 kHz)", "cores": cores, "kind": "reference",
+                           "sample": f"the same {16 * cores} trials through oracle/_ref/hga_optimized (the reference's extensions/hga/hga_optimized.pyx, compiled "
+                                     "unmodified) + scipy.signal.sosfilt x 2, driven as local/units.py:145-161 drives them; total stream-seconds / wall time of the pool.map call",
+                           "one_core": {"value": sec_r / t_r, "unit": "stream-seconds/s", "cores": 1, "sample": "8 trials, one process"}}
+            except Exception as e:                                  # e.g. another Python ABI than the module was built for
+                hga_ref = {"error": f"{type(e).__name__}: {e}"}
     _cpu_job((10_001, 3))
     t0 = time.time()
     one = sum(_cpu_job((s, FRAMES)) for s in range(4))              # four 1-s utterances on ONE core (this process)
@@ -115,6 +158,7 @@ def cpu_baseline(utt_per_core=2):
                               "oracle/liboracle.so (DF2T cascade + frame buffer + log power; bit-equal to the reference's "
                               "scipy sosfilt + Cython chain); total stream-seconds / wall time of the pool.map call",
                     "sum_over_slowest_job_span": hga_seconds / max(r[1] for r in hga_res),
+                    "reference": hga_ref,
                     "one_core": {"value": sec1 / t1, "unit": "stream-seconds/s", "cores": 1, "sample": "8 trials, one process"}}}
 
 

@@ -51,7 +51,13 @@ wrap(gp.queue, "submit", "submit")
 wrap(gp.queue, "poll", "poll")
 wrap(gp.queue, "_launch", "launch")
 rows = []
+paced = "--paced" in sys.argv          # the amplifier's 40 ms cadence, the host polling in between (as bench.py's paced leg)
+t_start = time.perf_counter()
 for k in range(ticks):
+    if paced:
+        while time.perf_counter() < t_start + 0.04 * k:
+            gp.poll()
+            time.sleep(0.0005)
     for v in stages.values():
         v.clear()
     busy = gp.queue.in_flight
@@ -60,6 +66,10 @@ for k in range(ticks):
     ms = (time.perf_counter() - t0) * 1e3
     rows.append((busy > 0, ms, {a: sum(b) for a, b in stages.items()}))
 gp.flush()
+print("paced (40 ms cadence)" if paced else "ticks back to back")
+worst = sorted(rows[10:], key=lambda r: -r[1])[:5]
+for r in worst:
+    print("   slowest ticks: %.3f ms  " % r[1] + "  ".join("%s %.3f" % kv for kv in r[2].items()))
 for flag in (False, True):
     sel = [r for r in rows[10:] if r[0] == flag]
     if not sel:
