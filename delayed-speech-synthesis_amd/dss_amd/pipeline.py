@@ -214,7 +214,8 @@ class GatedStreamingPipeline(_DecoderMixin):
         self.asynchronous = bool(asynchronous)
         self.queue = SegmentSynthesisQueue(self.gate, self.vocoder, n_channels, self.seg_cap, decoder_factory=factory,
                                            decoder_module=self.decoder, n_lanes=n_lanes if asynchronous else 1,
-                                           rows_per_job=min(rows_per_job, n_streams) if asynchronous else n_streams)
+                                           rows_per_job=min(rows_per_job, n_streams) if asynchronous else n_streams,
+                                           threaded=asynchronous)
         mean = np.zeros(n_channels) if channel_means is None else np.asarray(channel_means, dtype=np.float64)
         std = np.ones(n_channels) if channel_stds is None else np.asarray(channel_stds, dtype=np.float64)
         self.mean, self.std = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
@@ -263,6 +264,18 @@ class GatedStreamingPipeline(_DecoderMixin):
     def poll(self):
         """Segments finished since the last push()/poll() (a host between ticks may call this as often as it likes)."""
         return self.queue.poll()
+
+    def close(self):
+        """Stop the queue's worker thread and release its lanes (also done when the pipeline is dropped)."""
+        q = getattr(self, "queue", None)
+        if q is not None:
+            q.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def flush(self):
         """Wait for every segment that has closed so far; returns their (stream, previous_frames, pcm)."""

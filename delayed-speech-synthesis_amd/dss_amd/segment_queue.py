@@ -10,10 +10,13 @@ runs them on side streams:
     one ragged vocoder call  (a LANE of the streams' LPCNetBatch: row i continues the vocoder state of ITS stream, units.py:524)
     one asynchronous copy of the PCM into page-locked host memory, one event
 
-per job.  A job takes what is waiting when a lane is free -- at most one segment per stream, a stream's segments strictly in
+per job, issued by a WORKER THREAD of the queue (the HIP calls of a job, ~0.2 ms of host time on a cold GPU, and the copy of
+finished PCM out of the page-locked buffers are then no part of any tick; the thread sleeps on a condition variable while
+nothing is open and looks at its lanes' events every 0.2 ms while something is).  A job takes what is waiting when a lane is free -- at most one segment per stream, a stream's segments strictly in
 closing order (its next segment waits until the previous one's job has finished: the vocoder state carries over) -- so
 segments that closed on different streams are synthesised side by side and nothing is ever reordered within a stream.
-``poll()`` returns the segments finished since the last call; it never waits.
+``poll()`` returns the segments finished since the last call; it never waits.  ``threaded=False`` keeps everything on the
+caller's thread (jobs are then launched and retired inside ``poll()`` / ``drain()``): the blocking mode uses it.
 
 Lanes: each has its own HIP stream, decoder scratch, vocoder scratch and result buffer.  ROCm maps streams onto
 ``GPU_MAX_HW_QUEUES`` hardware queues (4 by default) and two streams that share one run their kernels one after the other:
@@ -25,6 +28,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import threading
 import time
 from typing import List, Optional
 
@@ -94,7 +98,8 @@ class _Lane:
 
 class SegmentSynthesisQueue:
     def __init__(self, gate, vocoder: LPCNetBatch, n_features: int, seg_cap: int, decoder_factory=None, decoder_module=None,
-                 n_lanes: Optional[int] = None, rows_per_job: int = 32, pool_rows: Optional[int] = None, n_out: int = 20):
+                 n_lanes: Optional[int] = None, rows_per_job: int = 32, pool_rows: Optional[int] = None, n_out: int = 20,
+                 threaded: bool = True):
         """gate: the SpeechGateGPU whose completed segments are taken; vocoder: the LPCNetBatch with one slot per stream.
         decoder_factory(rows, frames) -> BiLstmDecoderGPU (one per lane: each owns its layer buffers), or None: then
         decoder_module (any torch module with the reference's call signature) runs row by row on the lane's stream."""
@@ -118,7 +123,17 @@ class SegmentSynthesisQueue:
         self.latencies_ms: list = []                          # segment closed (submit) -> PCM seen on the host (poll)
         self.jobs_launched = 0
         self.segments_done = 0
+        self._open = 0                                        # segments submitted and not yet retired
+        self.device = vocoder.device
         self._warm_up()
+        # shared between the caller's thread (submit / poll / drain) and the worker: pending, the free lists, finished, counters
+        self._cv = threading.Condition(threading.RLock())
+        self._stop = False
+        self._error = None
+        self._thread = None
+        if threaded:
+            self._thread = threading.Thread(target=self._worker, name="dss-segment-queue", daemon=True)
+            self._thread.start()
 
     def _warm_up(self):
         """The first launch of the sample-rate kernels in a process loads their code object (milliseconds): pay that here, on a
@@ -142,15 +157,20 @@ class SegmentSynthesisQueue:
         for ln in lengths:
             if ln > self.cap:
                 raise ValueError(f"segment of {ln} frames exceeds max_segment_frames={self.cap}")
-        while len(self._free_rows) < n:                       # pool exhausted: wait for a job (never in a paced run)
-            self._dispatch()
-            if not self._wait_one():
-                raise RuntimeError("segment pool exhausted with no job in flight")
-        rows = [self._free_rows.pop() for _ in range(n)]
+        self._raise_worker_error()
+        with self._cv:
+            while len(self._free_rows) < n:                   # pool exhausted: wait for a job (never in a paced run)
+                if self._thread is not None:
+                    self._cv.wait(0.001)
+                    self._raise_worker_error()
+                else:
+                    self._dispatch()
+                    if not self._wait_one():
+                        raise RuntimeError("segment pool exhausted with no job in flight")
+            rows = [self._free_rows.pop() for _ in range(n)]
+            ev = self._free_events.pop() if self._free_events else None
         self.gate.collect_torch(streams, events, rows, self.pool, hip_stream=ts)
-        if self._free_events:
-            ev = self._free_events.pop()
-        else:
+        if ev is None:
             ev = L.dss_event_create()
             if not ev:
                 raise _lib.DssError(L.dss_last_error().decode())
@@ -158,9 +178,17 @@ class SegmentSynthesisQueue:
         _lib.check(L.dss_event_record(ev, ts))
         ready = _Ready(ev)
         now = time.perf_counter()
-        for s, ln, row, tag in zip(streams, lengths, rows, tags):
-            ready.refs += 1
-            self.pending.append(_Segment(int(s), int(ln), row, tag, ready, now))
+        with self._cv:
+            for s, ln, row, tag in zip(streams, lengths, rows, tags):
+                ready.refs += 1
+                self.pending.append(_Segment(int(s), int(ln), row, tag, ready, now))
+            self._open += n
+            self._cv.notify_all()
+
+    def _raise_worker_error(self):
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise RuntimeError("segment synthesis worker failed") from e
 
     # ---- side streams -----------------------------------------------------------------------------------------
     def _launch(self, lane: _Lane, job: List[_Segment]):
@@ -188,22 +216,25 @@ class SegmentSynthesisQueue:
         lane.job, lane.job_frames = job, fmax
         self.jobs_launched += 1
         for sg in job:
-            self.busy[sg.stream] = True
             sg.ready.refs -= 1
             if sg.ready.refs == 0:                            # every segment of that tick has been launched behind a wait on it
-                self._free_events.append(sg.ready.event)
+                self._free_events.append(sg.ready.event)      # (list.append: atomic; submit pops under the lock)
 
     def _retire(self, lane: _Lane):
         job, fmax = lane.job, lane.job_frames
         host = lane.host[: len(job) * fmax * FRAME_SIZE].reshape(len(job), fmax * FRAME_SIZE)
         now = time.perf_counter()
-        for k, sg in enumerate(job):
-            self.finished.append((sg.stream, sg.tag, host[k, : sg.length * FRAME_SIZE].copy()))
-            self.latencies_ms.append((now - sg.t_close) * 1e3)
-            self.busy[sg.stream] = False
-            self._free_rows.append(sg.row)
-        self.segments_done += len(job)
+        done = [(sg.stream, sg.tag, host[k, : sg.length * FRAME_SIZE].copy()) for k, sg in enumerate(job)]
         lane.job = None
+        with self._cv:
+            self.finished += done
+            for sg in job:
+                self.latencies_ms.append((now - sg.t_close) * 1e3)
+                self.busy[sg.stream] = False
+                self._free_rows.append(sg.row)
+            self.segments_done += len(job)
+            self._open -= len(job)
+            self._cv.notify_all()
 
     def _wait_one(self) -> bool:
         for lane in self.lanes:
@@ -213,49 +244,97 @@ class SegmentSynthesisQueue:
                 return True
         return False
 
-    def _dispatch(self):
-        if not self.pending:
-            return
-        for lane in self.lanes:
-            if lane.job is not None or not self.pending:
-                continue
-            job, keep, taken = [], collections.deque(), set()
-            for sg in self.pending:                           # closing order; a stream's later segment never overtakes its earlier one
-                if len(job) < self.R and not self.busy[sg.stream] and sg.stream not in taken:
-                    job.append(sg)
-                else:
-                    keep.append(sg)
-                taken.add(sg.stream)
-            if not job:
-                return
+    def _take_job(self):
+        """The next job out of `pending` (call with the lock held): closing order, at most one segment per stream, none of a
+        stream that has a job in flight -- a stream's later segment never overtakes its earlier one."""
+        job, keep, taken = [], collections.deque(), set()
+        for sg in self.pending:
+            if len(job) < self.R and not self.busy[sg.stream] and sg.stream not in taken:
+                job.append(sg)
+            else:
+                keep.append(sg)
+            taken.add(sg.stream)
+        if job:
             self.pending = keep
+            for sg in job:
+                self.busy[sg.stream] = True
+        return job
+
+    def _dispatch(self) -> bool:
+        did = False
+        for lane in self.lanes:
+            if lane.job is not None:
+                continue
+            with self._cv:
+                job = self._take_job() if self.pending else []
+            if not job:
+                break
             self._launch(lane, job)
+            did = True
+        return did
+
+    def _step(self) -> bool:
+        """Retire what has finished, start what can start (worker thread, or the caller's in the unthreaded form)."""
+        did = False
+        for lane in self.lanes:
+            if lane.job is not None and _lib.check(self._L.dss_event_query(lane.done)) == 1:
+                self._retire(lane)
+                did = True
+        return self._dispatch() or did
+
+    def _worker(self):
+        try:
+            _lib.check(self._L.dss_set_device(self.device))
+            torch.cuda.set_device(self.device)
+            while True:
+                did = self._step()
+                with self._cv:
+                    if self._stop:
+                        return
+                    if self._open == 0:
+                        self._cv.wait()                       # nothing open: sleep until submit() or close()
+                    elif not did:
+                        self._cv.wait(0.0002)                 # jobs in flight: look at their events again in 0.2 ms (or on submit)
+        except BaseException as e:                            # surfaces on the caller's next submit / poll / drain
+            self._error = e
+            with self._cv:
+                self._cv.notify_all()
 
     def poll(self):
         """Segments finished since the last call, as (stream, tag, pcm int16 host array), a stream's own in closing order.
-        Starts waiting segments on free lanes.  Never blocks."""
-        L = self._L
-        for lane in self.lanes:
-            if lane.job is not None and _lib.check(L.dss_event_query(lane.done)) == 1:
-                self._retire(lane)
-        self._dispatch()
-        out, self.finished = self.finished, []
+        Never blocks.  (Unthreaded form: also retires finished jobs and starts waiting segments on free lanes.)"""
+        self._raise_worker_error()
+        if self._thread is None:
+            self._step()
+        with self._cv:
+            out, self.finished = self.finished, []
         return out
 
     @property
     def in_flight(self) -> int:
-        return len(self.pending) + sum(len(l.job) for l in self.lanes if l.job is not None)
+        return self._open
 
     def drain(self):
         """Wait for everything submitted so far; returns what poll() would have returned over that time."""
         out = self.poll()
-        while self.in_flight:
-            if not self._wait_one():
+        while self._open:
+            if self._thread is not None:
+                with self._cv:
+                    if self._open and not self.finished and self._error is None:
+                        self._cv.wait(0.001)
+            elif not self._wait_one():
                 self._dispatch()
             out += self.poll()
         return out
 
     def close(self):
+        th = getattr(self, "_thread", None)
+        if th is not None:
+            with self._cv:
+                self._stop = True
+                self._cv.notify_all()
+            th.join(timeout=5.0)
+            self._thread = None
         for lane in getattr(self, "lanes", []):
             lane.close()
         self.lanes = []
