@@ -1421,8 +1421,8 @@ struct dss_hga {
     // optional fused front end
     int c_raw = 0, n_grids = 0;
     int *d_src_col = nullptr, *d_grid_of = nullptr, *d_comp_cols = nullptr, *d_comp_off = nullptr;
-    double *d_pre = nullptr, *d_raw = nullptr;
-    size_t pre_cap = 0, raw_cap = 0;
+    double *d_pre = nullptr, *d_raw = nullptr, *d_wire = nullptr;
+    size_t pre_cap = 0, raw_cap = 0, wire_cap = 0;
     double *d_zi0[2] = {nullptr, nullptr};
     double *d_in = nullptr, *d_out = nullptr;
     size_t in_cap = 0, out_cap = 0;
@@ -1483,7 +1483,7 @@ extern "C" void dss_hga_destroy(dss_hga *h)
     if (!h) return;
     hipSetDevice(h->device);
     void *ptrs[] = {h->d.zi, h->d.rows, h->d_zi0[0], h->d_zi0[1], h->d_in, h->d_out, h->d_src_col, h->d_grid_of,
-                    h->d_comp_cols, h->d_comp_off, h->d_pre, h->d_raw, h->d_zs[0], h->d_zs[1]};
+                    h->d_comp_cols, h->d_comp_off, h->d_pre, h->d_raw, h->d_wire, h->d_zs[0], h->d_zs[1]};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
 }
@@ -1657,6 +1657,26 @@ extern "C" int dss_hga_extract_raw_dev(dss_hga *h, const double *d_raw, int n, d
                                      h->d_comp_cols, h->d_comp_off, (hipStream_t)hip_stream);
     if (rc) return rc;
     return dss_hga_extract_dev(h, h->d_pre, n, d_out, apply_log, hip_stream);
+}
+
+// Payloads in wire format (float32, [stream][channel][sample]: the body of the amplifier's packets) -> frames.  With a front end
+// configured the payload carries its c_raw channels and goes through it, otherwise the extractor's own n_channels.
+extern "C" int dss_hga_extract_wire_dev(dss_hga *h, const float *d_payload, int n, double *d_out, int apply_log, void *hip_stream)
+{
+    if (!h || !d_payload || !d_out || n <= 0) { dss_set_error("bad arguments"); return DSS_EINVAL; }
+    DSS_HIP_CHECK(hipSetDevice(h->device));
+    const int c_in = h->c_raw ? h->c_raw : h->d.C;
+    const size_t need = (size_t)h->d.S * n * c_in;
+    if (need > h->wire_cap) {
+        if (h->d_wire) hipFree(h->d_wire);
+        h->d_wire = nullptr; h->wire_cap = 0;
+        DSS_HIP_CHECK(hipMalloc((void **)&h->d_wire, need * sizeof(double)));
+        h->wire_cap = need;
+    }
+    int rc = dss_launch_hga_wire(d_payload, h->d_wire, h->d.S, c_in, n, (hipStream_t)hip_stream);
+    if (rc) return rc;
+    return h->c_raw ? dss_hga_extract_raw_dev(h, h->d_wire, n, d_out, apply_log, hip_stream)
+                    : dss_hga_extract_dev(h, h->d_wire, n, d_out, apply_log, hip_stream);
 }
 
 extern "C" int dss_hga_extract_raw(dss_hga *h, const double *raw, int n, double *out)

@@ -223,6 +223,7 @@ int dss_launch_hga(const DssHgaDev &h, const double *d_data, const DssHgaFrontDe
                    int W, double *d_out, int apply_log, hipStream_t s);
 int dss_launch_hga_frontend(const double *d_raw, double *d_pre, int S, int n, int c_raw, int C, const int *src_col,
                             const int *grid_of, int n_grids, const int *comp_cols, const int *comp_off, hipStream_t s);
+int dss_launch_hga_wire(const float *d_payload, double *d_rows, int S, int C, int n, hipStream_t s);
 int dss_launch_hga_reset(const DssHgaDev &h, const double *d_zi_hg, const double *d_zi_fh, hipStream_t s);
 int dss_launch_log_power(const double *d_data, int T, int C, int sr, float wl, float ws, int W, double *d_out,
                          int apply_log, hipStream_t s);

@@ -596,6 +596,34 @@ hga_frontend_kernel(const double *__restrict__ raw, double *__restrict__ pre, in
     }
 }
 
+// Amplifier payloads as they arrive on the wire -- float32, channel-major: [stream][channel][sample] (the body of a BCI2000
+// packet behind its 7-byte header, reference local/units.py:78-82 and development_amplifier.py:14-25) -- to the float64
+// time-major rows [stream][sample][channel] every other entry point takes: what ZMQConnector.interpret_bytes does on the host
+// with reshape + transpose + astype(float64), for all streams at once.  float32 -> float64 is exact, so results do not change.
+// One workgroup per stream; the payload goes through LDS so that both the read and the write are linear.
+__global__ void __launch_bounds__(256) hga_wire_kernel(const float *__restrict__ payload, double *__restrict__ rows, int C, int n)
+{
+    extern __shared__ float wtile[];                          // [channel][sample], as it arrived
+    const int s = blockIdx.x, total = C * n;
+    const float *src = payload + (size_t)s * total;
+    for (int k = threadIdx.x; k < total; k += 256) wtile[k] = src[k];
+    __syncthreads();
+    double *dst = rows + (size_t)s * total;
+    for (int k = threadIdx.x; k < total; k += 256) {
+        const int t = k / C, c = k - t * C;
+        dst[k] = (double)wtile[c * n + t];
+    }
+}
+
+int dss_launch_hga_wire(const float *d_payload, double *d_rows, int S, int C, int n, hipStream_t s)
+{
+    const size_t lds = (size_t)C * n * sizeof(float);
+    if (lds > 64 * 1024) { dss_set_error("wire packet of %d channels x %d samples exceeds the 64 KB tile", C, n); return DSS_EINVAL; }
+    hipLaunchKernelGGL(hga_wire_kernel, dim3(S), dim3(256), lds, s, d_payload, d_rows, C, n);
+    DSS_HIP_CHECK(hipGetLastError());
+    return DSS_OK;
+}
+
 int dss_launch_hga_frontend(const double *d_raw, double *d_pre, int S, int n, int c_raw, int C, const int *src_col,
                             const int *grid_of, int n_grids, const int *comp_cols, const int *comp_off, hipStream_t st)
 {

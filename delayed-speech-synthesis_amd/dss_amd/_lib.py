@@ -105,6 +105,7 @@ def _declare(L):
         "dss_hga_set_frontend": (i, [vp, i, vp, vp, i, vp, vp]),
         "dss_hga_extract_raw": (i, [vp, vp, i, vp]),
         "dss_hga_extract_raw_dev": (i, [vp, vp, i, vp, i, vp]),
+        "dss_hga_extract_wire_dev": (i, [vp, vp, i, vp, i, vp]),
         "dss_hga_set_zscore": (i, [vp, vp, vp]),
         "dss_selftest_hga_force_path": (i, [vp, i]),
     }

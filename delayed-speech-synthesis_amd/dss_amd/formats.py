@@ -31,6 +31,16 @@ def parse_packet(data: bytes) -> np.ndarray:
     return np.ascontiguousarray(body.reshape(n_ch, n_smp).T, dtype=np.float64)
 
 
+def packet_payload(data: bytes) -> np.ndarray:
+    """One amplifier packet -> its body as it is: float32 (n_channels, n_samples), a VIEW of the bytes (no transpose, no
+    conversion).  S of them stacked are what ``HgaExtractorGPU.extract_wire_torch`` / ``GatedStreamingPipeline.push_wire`` take:
+    the transpose and the float64 conversion of ``parse_packet`` then run on the device."""
+    if len(data) < PACKET_HEADER.size:
+        raise ValueError("packet shorter than its 7-byte header")
+    _, _, _, n_ch, n_smp = PACKET_HEADER.unpack_from(data)
+    return np.frombuffer(data, dtype="<f4", count=n_ch * n_smp, offset=PACKET_HEADER.size).reshape(n_ch, n_smp)
+
+
 def build_packet(samples: np.ndarray) -> bytes:
     """Inverse of parse_packet: (n_samples, n_channels) -> packet bytes (development_amplifier.py:14-25)."""
     s = np.asarray(samples)

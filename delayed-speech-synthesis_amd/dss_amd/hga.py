@@ -174,6 +174,23 @@ class HgaExtractorGPU:
         assert got == W
         return out
 
+    def extract_wire_torch(self, payload, apply_log: bool = True, stream=None):
+        """Payloads in wire format: CUDA float32 (S, c_in, n), channel-major -- the bodies of the amplifier's packets
+        (``dss_amd.formats.packet_payload``), c_in = c_raw with a front end configured, else C -> (S, W, C) float64 frames.  The
+        reshape / transpose / astype(float64) of ZMQConnector.interpret_bytes (units.py:78-82) runs on the device."""
+        import torch
+        c_in = getattr(self, "c_raw", None) or self.C
+        assert payload.is_cuda and payload.dtype == torch.float32 and payload.is_contiguous()
+        if payload.dim() != 3 or payload.shape[0] != self.S or payload.shape[1] != c_in:
+            raise ValueError(f"expected ({self.S}, {c_in}, n) float32, got {tuple(payload.shape)}")
+        n = payload.shape[2]
+        W = self.frames_for(n)
+        out = torch.empty((self.S, W, self.C), dtype=torch.float64, device=payload.device)
+        s = torch.cuda.current_stream(payload.device).cuda_stream if stream is None else stream
+        got = _lib.check(self._L.dss_hga_extract_wire_dev(self._h, payload.data_ptr(), n, out.data_ptr(), int(apply_log), s))
+        assert got == W
+        return out
+
     def extract_torch(self, data, apply_log: bool = True, out=None, stream=None):
         """Device-resident: (S, n, C) float64 CUDA tensor -> (S, W, C) float64 CUDA tensor."""
         import torch

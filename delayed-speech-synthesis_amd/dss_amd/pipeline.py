@@ -186,7 +186,8 @@ class GatedStreamingPipeline(_DecoderMixin):
                  channel_means: Optional[np.ndarray] = None, channel_stds: Optional[np.ndarray] = None,
                  decoder: Optional[torch.nn.Module] = None, vad: Optional[torch.nn.Module] = None, seed: int = 0,
                  max_segment_frames: Optional[int] = None, use_vad_kernel: bool = True, use_decoder_kernel: bool = True,
-                 asynchronous: bool = True, n_lanes: Optional[int] = None, rows_per_job: int = 32):
+                 asynchronous: bool = True, n_lanes: Optional[int] = None, rows_per_job: int = 32,
+                 pool_rows: Optional[int] = None):
         self.S, self.C, self.packet = n_streams, n_channels, packet
         self.hga = HgaExtractorGPU(n_streams, n_channels, fs=fs)
         self.decoder = self._make_decoder(n_channels, decoder, seed)
@@ -215,7 +216,7 @@ class GatedStreamingPipeline(_DecoderMixin):
         self.queue = SegmentSynthesisQueue(self.gate, self.vocoder, n_channels, self.seg_cap, decoder_factory=factory,
                                            decoder_module=self.decoder, n_lanes=n_lanes if asynchronous else 1,
                                            rows_per_job=min(rows_per_job, n_streams) if asynchronous else n_streams,
-                                           threaded=asynchronous)
+                                           threaded=asynchronous, pool_rows=pool_rows)
         mean = np.zeros(n_channels) if channel_means is None else np.asarray(channel_means, dtype=np.float64)
         std = np.ones(n_channels) if channel_stds is None else np.asarray(channel_stds, dtype=np.float64)
         self.mean, self.std = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
@@ -227,6 +228,7 @@ class GatedStreamingPipeline(_DecoderMixin):
         self.last_labels = None           # raw VAD decisions and z-scored frames of the last tick (test taps)
         self.last_z = None
         self.segments_closed = 0
+        self._in_wire = None
 
     @torch.no_grad()
     def push(self, packets: np.ndarray):
@@ -234,7 +236,23 @@ class GatedStreamingPipeline(_DecoderMixin):
         speech segments whose audio has FINISHED since the last call (asynchronous mode; a stream's segments always in
         closing order), or the segments that closed on this tick (asynchronous=False: the tick waits for them)."""
         self._in.copy_(torch.from_numpy(np.ascontiguousarray(packets, dtype=np.float64)))
-        hga = self.hga.extract_torch(self._in, apply_log=True)                       # (S, W, C) float64
+        return self._after_extract(self.hga.extract_torch(self._in, apply_log=True))    # (S, W, C) float64
+
+    @torch.no_grad()
+    def push_wire(self, payloads: np.ndarray):
+        """The same tick from the packets' bodies as they arrive on the wire: host float32 (S, C, packet), channel-major
+        (``dss_amd.formats.packet_payload`` of each stream's packet, stacked).  Half the bytes cross the bus, and the per-packet
+        reshape / transpose / astype(float64) of ZMQConnector.interpret_bytes (units.py:78-82) runs on the device for all
+        streams at once; the frames -- and everything behind them -- are bit-identical to ``push`` on the parsed packets."""
+        p = np.ascontiguousarray(payloads, dtype=np.float32)
+        if p.shape != (self.S, self.C, self.packet):
+            raise ValueError(f"expected payloads ({self.S}, {self.C}, {self.packet}) float32, got {p.shape}")
+        if self._in_wire is None:
+            self._in_wire = torch.empty((self.S, self.C, self.packet), dtype=torch.float32, device="cuda")
+        self._in_wire.copy_(torch.from_numpy(p))
+        return self._after_extract(self.hga.extract_wire_torch(self._in_wire, apply_log=True))
+
+    def _after_extract(self, hga):
         W = hga.shape[1]
         if W == 0:
             return self.queue.poll()

@@ -251,6 +251,13 @@ int dss_hga_extract_raw_dev(dss_hga *h, const double *d_raw, int n, double *d_ou
 /* Device-resident form: d_data / d_out device pointers; log applied on the device (OCML log, <= 1 ulp
  * from the host's) when apply_log != 0, else out = mean power + 0.01. */
 int dss_hga_extract_dev(dss_hga *h, const double *d_data, int n, double *d_out, int apply_log, void *hip_stream);
+/* The same from payloads in WIRE format: d_payload (n_streams, c_in, n) float32, channel-major -- the body of the amplifier's
+ * packets behind their 7-byte header (local/units.py:78-82: '=BBB HH' + float32[n_channels x n_samples];
+ * development_amplifier.py:14-25), c_in = c_raw when a front end is configured, else n_channels.  One more small launch does on
+ * the device what ZMQConnector.interpret_bytes does per packet on the host (reshape, transpose, astype(float64)); float32 ->
+ * float64 is exact, the frames are those of dss_hga_extract_raw_dev / dss_hga_extract_dev on the converted rows, bit for bit.
+ * Half the bytes cross the bus and no stream's packet is touched by the host. */
+int dss_hga_extract_wire_dev(dss_hga *h, const float *d_payload, int n, double *d_out, int apply_log, void *hip_stream);
 /* Optional last step of the reference's feature chain inside the extractor's launch: ZScoreNormalization,
  * (frame - means[c]) / stds[c] (local/common.py:367-376; decode_online.py:88-97 puts it behind HighGammaActivity as a
  * post-transform).  means / stds: host arrays of n_channels doubles, both NULL to clear.  The device-resident entry

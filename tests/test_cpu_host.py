@@ -84,6 +84,11 @@ def test_wire_and_disk_formats(tmp_path):
     import LPCNet
     assert np.array_equal(np.stack(list(LPCNet.LPCFeatureFile(str(tmp_path / "utt.f32")))), feats36[:, :20])
     assert F.pcm_to_s16le(np.array([1, -2, 32767], dtype=np.int16)) == struct.pack("<3h", 1, -2, 32767)
+    # the packet body as it is (what the device-side ingest takes): a float32 view, channel-major, no copy
+    pk = F.build_packet(np.arange(12, dtype=np.float64).reshape(4, 3))
+    body = F.packet_payload(pk)
+    assert body.dtype == np.float32 and body.shape == (3, 4) and not body.flags.owndata
+    assert np.array_equal(body.T.astype(np.float64), F.parse_packet(pk))
 
 
 def test_electrode_tables_and_frontend_description():

@@ -265,8 +265,8 @@ def test_asynchronous_segment_synthesis_equals_the_blocking_path():
     for k in range(ticks):
         want += ref.push(ecog[:, k * 40:(k + 1) * 40])
     assert len(want) >= 20 and ref.flush() == []
-    for lanes, rows in ((3, 32), (1, 2), (2, 1)):
-        pipe = GatedStreamingPipeline(S, C, asynchronous=True, n_lanes=lanes, rows_per_job=rows, **kw)
+    for lanes, rows, pool in ((3, 32, None), (1, 2, None), (2, 1, 3)):     # the last one: a pool of three segment buffers -- submit() has to wait for rows
+        pipe = GatedStreamingPipeline(S, C, asynchronous=True, n_lanes=lanes, rows_per_job=rows, pool_rows=pool, **kw)
         got, seen_pending = [], 0
         for k in range(ticks):
             got += pipe.push(ecog[:, k * 40:(k + 1) * 40])
@@ -281,7 +281,63 @@ def test_asynchronous_segment_synthesis_equals_the_blocking_path():
             for (_, x), (_, y) in zip(a, b):
                 assert x.dtype == np.int16 and np.array_equal(x, y), (lanes, rows, s)
         assert len(pipe.queue.latencies_ms) == len(got)
+        pipe.close()
+        assert pipe.queue._thread is None and pipe.queue.lanes == []
         del pipe
+
+
+def test_gated_pipeline_from_wire_format_packets():
+    """push_wire (packet bodies as they arrive: float32, channel-major) against push on the packets parsed on the host: the same
+    labels, frames, segments and PCM."""
+    from dss_amd import formats as F, lpcnet
+    from dss_amd.pipeline import GatedStreamingPipeline
+    lpcnet.load_model(synthetic_blob(0))
+    S, C, ticks = 3, 64, 50
+    rng = np.random.default_rng(31)
+    env = _loud_quiet(rng, S, ticks * 40, 20.0, 400.0)
+    kw = dict(buffer_size=300, context_frames=8, channel_means=np.full(C, 7.4), vad=_ThresholdVAD(), max_segment_frames=300, asynchronous=False)
+    a, b = GatedStreamingPipeline(S, C, **kw), GatedStreamingPipeline(S, C, **kw)
+    n_seg = 0
+    for k in range(ticks):
+        x = rng.standard_normal((S, 40, C)) * env[:, k * 40:(k + 1) * 40, None]
+        packets = [F.build_packet(x[s]) for s in range(S)]
+        ga = a.push(np.stack([F.parse_packet(p) for p in packets]))
+        gb = b.push_wire(np.stack([F.packet_payload(p) for p in packets]))
+        assert torch.equal(a.last_z, b.last_z) and torch.equal(a.last_labels, b.last_labels)
+        assert [(s, q) for s, q, _ in ga] == [(s, q) for s, q, _ in gb]
+        for (_, _, u), (_, _, v) in zip(ga, gb):
+            assert np.array_equal(u, v)
+        n_seg += len(ga)
+    assert n_seg >= 3
+    a.close(); b.close()
+
+
+def test_segment_queue_refuses_and_reports():
+    """A segment longer than the queue's buffers is refused on the tick that closes it (nothing is truncated); a failure on the
+    worker thread surfaces on the caller's next call instead of vanishing with the thread."""
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import GatedStreamingPipeline
+    lpcnet.load_model(synthetic_blob(0))
+    S, C = 2, 64
+    rng = np.random.default_rng(5)
+    kw = dict(buffer_size=300, context_frames=8, channel_means=np.full(C, 7.4), vad=_ThresholdVAD())
+    pipe = GatedStreamingPipeline(S, C, max_segment_frames=20, **kw)                  # speech runs of ~60 frames + 16 of context
+    env = np.concatenate([np.full(200, 20.0), np.full(600, 400.0), np.full(800, 20.0)])
+    ecog = rng.standard_normal((S, env.size, C)) * env[None, :, None]
+    with pytest.raises(ValueError, match="exceeds max_segment_frames"):
+        for k in range(env.size // 40):
+            pipe.push(ecog[:, k * 40:(k + 1) * 40])
+    pipe.close()
+    pipe = GatedStreamingPipeline(S, C, max_segment_frames=300, **kw)
+
+    def boom(lane, job):
+        raise RuntimeError("injected")
+    pipe.queue._launch = boom
+    with pytest.raises(RuntimeError, match="worker failed"):
+        for k in range(env.size // 40):
+            pipe.push(ecog[:, k * 40:(k + 1) * 40])
+        pipe.flush()
+    pipe.close()
 
 
 def test_asynchronous_queue_with_a_module_of_another_architecture():

@@ -236,3 +236,35 @@ def test_front_end_and_zscore_against_the_reference_classes(golden):
     z.set_zscore(g["zs_means"].reshape(-1), g["zs_stds"].reshape(-1))
     got = np.concatenate([z.extract_raw(raw[None, a:a + 40])[0] for a in (0, 40)])
     assert np.array_equal(got, (frames - g["zs_means"]) / g["zs_stds"])
+
+
+def test_wire_format_payloads_equal_the_parsed_packets(golden):
+    """dss_hga_extract_wire_dev: the bodies of the amplifier's packets as they arrive (float32, channel-major; formats.packet_payload)
+    give, bit for bit, the frames of the packets parsed on the host as the reference's ZMQConnector.interpret_bytes parses them
+    (formats.parse_packet: reshape, transpose, astype(float64)) -- plain 64-channel packets and raw 129-channel packets through the
+    front end, several packets with carried state, an odd packet length."""
+    import torch
+    from dss_amd import formats as F
+    from dss_amd.electrodes import reference_frontend
+    from dss_amd.hga import HgaExtractorGPU
+    S = 5
+    rng = np.random.default_rng(11)
+    for c_in, front in ((64, False), (129, True)):
+        a = HgaExtractorGPU(S, 64, filters=_filters(golden))
+        b = HgaExtractorGPU(S, 64, filters=_filters(golden))
+        if front:
+            a.set_frontend(129, *reference_frontend())
+            b.set_frontend(129, *reference_frontend())
+        n_frames = 0
+        for n in (40, 40, 37, 40, 120):
+            packets = [F.build_packet((rng.standard_normal((n, c_in)) * 40.0)) for _ in range(S)]      # bytes, as on the socket
+            parsed = np.stack([F.parse_packet(p) for p in packets])                                    # (S, n, c_in) float64
+            payload = np.stack([F.packet_payload(p) for p in packets])                                 # (S, c_in, n) float32
+            assert payload.dtype == np.float32 and np.array_equal(payload.transpose(0, 2, 1).astype(np.float64), parsed)
+            want = (a.extract_raw_torch if front else a.extract_torch)(torch.from_numpy(parsed).cuda())
+            got = b.extract_wire_torch(torch.from_numpy(payload).cuda())
+            assert got.shape == want.shape and torch.equal(got, want), (c_in, n)
+            n_frames += got.shape[1]
+        assert n_frames > 20
+    with pytest.raises(ValueError):
+        b.extract_wire_torch(torch.zeros((S, 64, 40), dtype=torch.float32, device="cuda"))            # front end set: 129 channels expected

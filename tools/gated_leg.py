@@ -32,7 +32,9 @@ def make_input():
             n_ = int(rng.integers(1000, 4000))
             env[s_, t_:t_ + n_] = 60.0 if loud else 3.0
             loud, t_ = not loud, t_ + n_
-    return [(rng.standard_normal((S, 40, 64)) * env[:, 40 * k:40 * k + 40, None]) for k in range(TICKS)]
+    # float32-valued, as an amplifier's packets are (local/units.py:78-82): the float64 rows and the wire-format payloads of the
+    # two kinds of pass then carry the same numbers
+    return [(rng.standard_normal((S, 40, 64)) * env[:, 40 * k:40 * k + 40, None]).astype(np.float32).astype(np.float64) for k in range(TICKS)]
 
 
 def detector():
@@ -48,13 +50,16 @@ def detector():
     return vad
 
 
-def run(packets, paced, asynchronous=True, n_lanes=None):
+def run(packets, paced, asynchronous=True, n_lanes=None, wire=False):
     import numpy as np
     from dss_amd.pipeline import GatedStreamingPipeline
     pct = lambda a, q: float(np.percentile(a, q)) if len(a) else None
     kw = {} if n_lanes is None else {"n_lanes": n_lanes}
     gp = GatedStreamingPipeline(S, 64, channel_means=np.full(64, 5.0), vad=detector(), max_segment_frames=1040,      # no segment can outgrow the 10.4 s of the leg
                                 asynchronous=asynchronous, **kw)
+    if wire:                                                     # the packets' bodies as they arrive: float32, channel-major
+        packets = [np.ascontiguousarray(p.transpose(0, 2, 1), dtype=np.float32) for p in packets]
+    push = gp.push_wire if wire else gp.push
     tick_ms, closing_ms, n_seg, seg_frames = [], [], 0, 0
     t_start = time.perf_counter()
     t_meas = t_start
@@ -75,7 +80,7 @@ def run(packets, paced, asynchronous=True, n_lanes=None):
             n_seg = seg_frames = 0
         closed_before = gp.segments_closed
         t0 = time.perf_counter()
-        got = gp.push(packets[k])
+        got = push(packets[k])
         ms = (time.perf_counter() - t0) * 1e3
         n_seg += len(got); seg_frames += sum(len(pcm) // FRAME for _, _, pcm in got)
         if k >= WARM:
@@ -102,6 +107,7 @@ def leg(n_lanes=None, blocking=False):
     stream_s = (TICKS - WARM) * 0.04
     unpaced = run(packets, False, n_lanes=n_lanes)
     paced = run(packets, True, n_lanes=n_lanes)
+    paced_wire = run(packets, True, n_lanes=n_lanes, wire=True)
     out = {"config": "128 streams x 40-sample packets through HGA -> VAD LSTM(150)x2 (csrc/vad_lstm.hip, one launch) -> gate kernel -> "
                      "event counts on the host; segments that close are collected (one launch on the tick's stream) and decoded + vocoded "
                      "on side streams (ragged csrc/bilstm_decoder.hip call + ragged LPCNet launch on a lane + PCM copy-out kernel per job; "
@@ -110,9 +116,12 @@ def leg(n_lanes=None, blocking=False):
            "stream_seconds": stream_s, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
            "unpaced": unpaced, "unpaced_wall_over_stream_time": unpaced["wall_s_incl_drain"] / stream_s,
            "paced_40ms": paced, "paced_wall_over_stream_time": paced["wall_s_incl_drain"] / stream_s,
+           "paced_40ms_wire_format_input": paced_wire,
            "note": "tick_* = wall time of push() over ALL measured ticks (host packet in -> event counts read, closing segments handed "
                    "to the queue, finished PCM handed back); segment_close_to_pcm = submit on the closing tick -> its PCM seen on the "
-                   "host by poll() (a 3.46-s segment is 140 ms of vocoder time at single-utterance speed).  BENCH_r04 (vocoding on the "
+                   "host (a 3.46-s segment is 140 ms of vocoder time at single-utterance speed).  *_wire_format_input: the same pass with "
+                   "push_wire(): each tick hands over the packets\' bodies as they arrive (float32, channel-major, 1.3 MB instead of 2.6 MB "
+                   "of parsed float64 rows) and the reshape / transpose / float64 conversion runs on the device (dss_hga_extract_wire_dev).  BENCH_r04 (vocoding on the "
                    "tick path): closing ticks p50 145 ms, about 21 s of wall time for these 10 s of streams."}
     if blocking:
         b = run(packets, False, asynchronous=False)
