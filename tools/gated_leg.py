@@ -61,6 +61,9 @@ def run(packets, paced, asynchronous=True, n_lanes=None, wire=False):
         packets = [np.ascontiguousarray(p.transpose(0, 2, 1), dtype=np.float32) for p in packets]
     push = gp.push_wire if wire else gp.push
     tick_ms, closing_ms, n_seg, seg_frames = [], [], 0, 0
+    import gc
+    gc.collect()
+    gc.disable()                                                 # a generation-2 collection inside a tick is milliseconds; a real-time host pins this too
     t_start = time.perf_counter()
     t_meas = t_start
     for k in range(TICKS):
@@ -91,6 +94,7 @@ def run(packets, paced, asynchronous=True, n_lanes=None, wire=False):
     got = gp.flush()
     n_seg += len(got); seg_frames += sum(len(pcm) // FRAME for _, _, pcm in got)
     wall = time.perf_counter() - t_meas
+    gc.enable()
     lat = list(gp.queue.latencies_ms)
     res = {"ticks": len(tick_ms), "tick_p50_ms": pct(tick_ms, 50), "tick_p99_ms": pct(tick_ms, 99), "tick_max_ms": max(tick_ms),
            "ticks_that_closed_a_segment": len(closing_ms), "closing_tick_p50_ms": pct(closing_ms, 50), "closing_tick_p99_ms": pct(closing_ms, 99),
