@@ -96,6 +96,9 @@
 #ifndef DSS_RELAY_MASK
 #define DSS_RELAY_MASK 0
 #endif
+#ifndef DSS_KNOCKOUT
+#define DSS_KNOCKOUT 0
+#endif
 #ifndef GB4H
 #define GB4H 32
 #endif
@@ -429,8 +432,13 @@ __device__ __forceinline__ void dss_role_a(SampleLds &L, float *hblk_lds, const 
             __syncthreads();                                                        // barrier B
             if (STAMP) { const unsigned t = DSS_NOW(); sa[4] += t - ta; ta = t; }
             else if (DSS_RELAY_STAMP) ta = DSS_NOW();
+#if DSS_KNOCKOUT      /* development builds only (results WRONG on purpose): what the relay's SIMD neighbours cost it, profiles/r5_latency_kernel_experiment.md */
+            if (!((DSS_KNOCKOUT & 1) && (wave == 2 || wave == 3)) && !((DSS_KNOCKOUT & 4) && (wave == 0 || wave == 1))) { DSS_H_CHAIN(L.state_a[DSS_NEW(cur)]) }
+            if (!((DSS_KNOCKOUT & 2) && (wave == 2 || wave == 3))) { DSS_ZR_PRODUCTS(L.state_a[DSS_NEW(cur)]) }
+#else
             DSS_H_CHAIN(L.state_a[DSS_NEW(cur)])                      // next sample's h chain, under GRU B
             DSS_ZR_PRODUCTS(L.state_a[DSS_NEW(cur)])                  // ... and its z/r block products (sums come later)
+#endif
             if (wave == DSS_SPEC_WAVE || wave < 2) {
                 // Speculation over all 256 possible excitation values of THIS sample, one candidate per lane of wave DSS_SPEC_WAVE
                 // (candidates 64..127), of waves 0, 1, which have the lightest B..C load of the dual-FC waves (128..255),
