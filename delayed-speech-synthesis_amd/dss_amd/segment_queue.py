@@ -49,6 +49,21 @@ def default_lanes() -> int:
     return max(1, min(7, q - 1))
 
 
+def select_job(pending, busy, max_rows):
+    """Which of the waiting segments (objects with a ``stream`` attribute, in closing order) start together: at most `max_rows`, at
+    most one per stream, none of a stream that has a job in flight (``busy[stream]``) -- and never a segment whose stream has an
+    EARLIER segment still waiting, whatever the reason that one was passed over: a stream's vocoder state carries from segment
+    to segment (units.py:524), so its segments run strictly in closing order.  Returns (job, the rest in unchanged order)."""
+    job, keep, seen = [], collections.deque(), set()
+    for sg in pending:
+        if len(job) < max_rows and not busy[sg.stream] and sg.stream not in seen:
+            job.append(sg)
+        else:
+            keep.append(sg)
+        seen.add(sg.stream)
+    return job, keep
+
+
 class _Segment:
     __slots__ = ("stream", "length", "row", "tag", "ready", "t_close")
 
@@ -245,15 +260,8 @@ class SegmentSynthesisQueue:
         return False
 
     def _take_job(self):
-        """The next job out of `pending` (call with the lock held): closing order, at most one segment per stream, none of a
-        stream that has a job in flight -- a stream's later segment never overtakes its earlier one."""
-        job, keep, taken = [], collections.deque(), set()
-        for sg in self.pending:
-            if len(job) < self.R and not self.busy[sg.stream] and sg.stream not in taken:
-                job.append(sg)
-            else:
-                keep.append(sg)
-            taken.add(sg.stream)
+        """The next job out of `pending` (call with the lock held); marks its streams busy."""
+        job, keep = select_job(self.pending, self.busy, self.R)
         if job:
             self.pending = keep
             for sg in job:
