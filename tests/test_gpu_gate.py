@@ -340,6 +340,40 @@ def test_segment_queue_refuses_and_reports():
     pipe.close()
 
 
+def test_asynchronous_path_at_full_size_128_streams():
+    """BASELINE config 5 as decode_online.py runs it, at its own sizes: 128 streams, ring 2000, context 50, the reference's detector and
+    decoder architectures on the library's kernels, seven lanes when the hardware queues allow.  Every segment that closes comes back
+    exactly once, per stream in closing order, with the blocking path's previous_frames and bit-identical PCM."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gated_leg
+    from dss_amd import lpcnet
+    from dss_amd.pipeline import GatedStreamingPipeline
+    lpcnet.load_model(synthetic_blob(0))
+    S, ticks = 128, 130
+    packets = gated_leg.make_input()[:ticks]
+    kw = dict(channel_means=np.full(64, 5.0), max_segment_frames=600)
+    ref = GatedStreamingPipeline(S, 64, vad=gated_leg.detector(), asynchronous=False, **kw)
+    pipe = GatedStreamingPipeline(S, 64, vad=gated_leg.detector(), **kw)
+    assert pipe.vad_gpu is not None and pipe.dec_gpu is not None and len(pipe.queue.lanes) >= 3
+    want, got = [], []
+    for k in range(ticks):
+        want += ref.push(packets[k])
+        got += pipe.push(packets[k])
+    got += pipe.flush()
+    assert len(want) >= 30 and len(got) == len(want) == pipe.segments_closed
+    by = {}
+    for s, p, pcm in want:
+        by.setdefault(s, []).append((p, pcm))
+    seen = {}
+    for s, p, pcm in got:
+        k = seen.get(s, 0)
+        assert k < len(by[s]) and by[s][k][0] == p and np.array_equal(by[s][k][1], pcm), (s, k)
+        seen[s] = k + 1
+    assert all(seen.get(s, 0) == len(v) for s, v in by.items())
+    ref.close(); pipe.close()
+
+
 def test_asynchronous_queue_with_a_module_of_another_architecture():
     """A decoder the kernels do not take (3 layers) runs as the PyTorch-ROCm module on the lane's stream: same PCM as the
     blocking path."""
